@@ -1,0 +1,191 @@
+/*
+ * rt_abi.h — C-ABI drop-in boundary for the per-pixel Monte Carlo render loop.
+ *
+ * The reference (firelion9/raytracing-course-hw-public) has no plugin/FFI layer;
+ * the one seam where the hot path is entered is the call
+ *
+ *     run_raytracer(const Scene &scene, Image &image)      src/main.cpp:37 -> src/raytracer.h:629
+ *
+ * Everything below replaces exactly that call (and what it owns: the two BVH
+ * builds of raytracer.h:440-447 and the per-pixel sample loop of raytracer.h:618-627).
+ * Plain pointers + sizes only; no C++ or torch types cross this boundary.
+ *
+ * Reference inputs consumed at the seam and their POD restatement here:
+ *   scene.objects[i].shape      (geometry.h:458-503, 3 x vec3)      -> rt_scene_desc.positions  (9 floats / triangle)
+ *   scene.objects[i].attrs      (geometry.h:633-637)                -> normals (9), texcoords (6), tangents (9)
+ *   scene.objects[i].material   (geometry.h:604-613, one per Object)-> material_ids[i] into rt_material_desc[]
+ *   material.*_tex pointers     (geometry.h:610-613)                -> texture indices, RT_TEX_NONE = built-in
+ *                                                                      WHITE_TEXTURE / NORMAL_UP (geometry.h:601-602)
+ *   Texture::data (color4 float = stb u8 / 255.0f, geometry.h:590-595) -> RGBA8 texels (the /255.0f and the per-lookup
+ *                                                                      pow(c, 2.2f) of geometry.h:525-527 are done
+ *                                                                      by bit-exact 256-entry tables)
+ *   scene.camera                (scene.h:60-72)                     -> rt_camera
+ *   scene.bg_color, scene.bg    (scene.h:75,81; main.cpp:28-31)     -> bg_color (bg texture is the 1x1 white default,
+ *                                                                      USE_ENV_MAP=false, config.h:37)
+ *   scene.ray_depth, samples    (scene.h:76-77)                     -> rt_scene_desc.ray_depth, rt_params.samples
+ * Reference output at the seam:
+ *   image.set_pixel(p_idx, render_pixel(...)) (raytracer.h:658) which tone-maps at once (image.h:40-42,79-82)
+ *                                                                   -> linear float3 framebuffer; tone-map/quantise is a
+ *                                                                      pure per-pixel host function applied afterwards
+ *                                                                      (rt_tonemap_rgb8, restating image.h:49-82).
+ * Errors: the reference throws std::runtime_error (caught in main.cpp:46-49). Nothing is thrown across this
+ * ABI: every entry point returns RT_OK or an error code and rt_last_error() holds the message.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+#define RT_TEX_NONE (-1)
+
+/* error codes */
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = 1,
+    RT_ERR_NO_DEVICE = 2,   /* HIP runtime / GPU missing: the product never falls back to a CPU path */
+    RT_ERR_HIP = 3,
+    RT_ERR_OOM = 4,
+    RT_ERR_IO = 5,
+    RT_ERR_FORMAT = 6,
+    RT_ERR_COMM = 7
+};
+
+/* RNG / transcendental policy of the sample loop.
+ *   RT_RNG_DEVICE : counter-seeded xoshiro128++ stream per (pixel, sample) + shared double-precision
+ *                   sin/cos polynomial (include/rt_devspec.h). Scheduling independent: any tiling / GPU
+ *                   count gives the same framebuffer. This is the production mode.
+ *   RT_RNG_REFERENCE : the reference's stream: std::minstd_rand seeded with the 256-pixel span index
+ *                   (raytracer.h:458,648; config.h:13) and the libstdc++-11 distribution algorithms,
+ *                   one sequential stream per span. On the GPU one lane walks one span (parity mode,
+ *                   not a performance mode). sin/cos still use the shared polynomial on the device.
+ */
+enum { RT_RNG_DEVICE = 0, RT_RNG_REFERENCE = 1 };
+
+typedef struct rt_camera {
+    float position[3];
+    float right[3];
+    float up[3];
+    float forward[3];
+    float fov_x; /* radians, as Camera::fov_x (scene.h:67) */
+} rt_camera;
+
+typedef struct rt_texture_desc {
+    uint32_t width;
+    uint32_t height;
+    const uint8_t *rgba8; /* width*height*4, row-major, as stbi_load(..., 4) returns (geometry.h:586) */
+} rt_texture_desc;
+
+typedef struct rt_material_desc {
+    float color[4];    /* material::color (geometry.h:605) */
+    float emission[3]; /* material::emission */
+    float roughness;
+    float metallic;
+    float ior;
+    int32_t color_tex;    /* index into textures or RT_TEX_NONE */
+    int32_t emissive_tex;
+    int32_t metallic_roughness_tex;
+    int32_t normal_tex;
+} rt_material_desc;
+
+typedef struct rt_scene_desc {
+    uint32_t abi_version; /* RT_ABI_VERSION */
+    uint32_t n_triangles;
+    const float *positions;       /* 9*n : a.xyz b.xyz c.xyz */
+    const float *normals;         /* 9*n */
+    const float *texcoords;       /* 6*n */
+    const float *tangents;        /* 9*n */
+    const uint32_t *material_ids; /* n */
+    uint32_t n_materials;
+    const rt_material_desc *materials;
+    uint32_t n_textures;
+    const rt_texture_desc *textures;
+    rt_camera camera;
+    float bg_color[3];
+    uint32_t ray_depth; /* Scene::ray_depth; 8 for glTF (scene.h:186, config.h:17) */
+} rt_scene_desc;
+
+typedef struct rt_params {
+    uint32_t width;
+    uint32_t height;
+    uint32_t samples;  /* SPP */
+    uint32_t rng_mode; /* RT_RNG_* */
+    uint64_t seed;     /* RT_RNG_DEVICE only */
+    /* Image sharding: this call renders pixel blocks  b  with  b % shard_count == shard_index,
+     * where block b = row-major pixels [b*shard_block, (b+1)*shard_block). Pixels of other shards are left
+     * untouched in fb_rgb. shard_count = 0 or 1 renders everything. shard_block must be a multiple of 256
+     * (the reference span, config.h:13) in RT_RNG_REFERENCE mode. */
+    uint32_t shard_index;
+    uint32_t shard_count;
+    uint32_t shard_block;
+    uint32_t flags; /* RT_FLAG_* */
+} rt_params;
+
+enum {
+    RT_FLAG_NONE = 0,
+    RT_FLAG_DEVICE_FB = 1 /* fb_rgb is a device pointer (HBM resident); no D2H copy */
+};
+
+/* Per-render statistics (optional out-parameter). Counters are layout independent event counts in the
+ * reference's terms: what the reference algorithm touches, not what caches absorb. */
+typedef struct rt_stats {
+    uint64_t samples;
+    uint64_t casts;          /* closest-hit traversals (raytracer.h:540-553) */
+    uint64_t nodes_visited;  /* BVH::intersect_ray invocations (bvh.h:195) */
+    uint64_t box_tests;      /* intersect(ray, aabb) calls (bvh.h:137) */
+    uint64_t tri_tests;      /* intersect(ray, triangle) calls (bvh.h:52) */
+    uint64_t shaded_hits;    /* to_intersection_info on closest hits (bvh.h:176) */
+    uint64_t light_queries;  /* bvh_mix_dist::pdf calls (raytracer.h:363) */
+    uint64_t light_nodes;
+    uint64_t light_box_tests;
+    uint64_t light_tri_tests;
+    uint64_t light_hits;
+    uint64_t texel_fetches;  /* texels read by Texture::sample (geometry.h:559-568), 4 per non-1x1 lookup */
+    double kernel_ms;        /* device time of the render kernel(s), HIP events on the launch stream */
+    double total_ms;         /* wall time of rt_render */
+} rt_stats;
+
+typedef struct rt_scene rt_scene; /* opaque: device-resident scene + both BVHs */
+
+/* Replaces RaytracerStaticContext(scene) (raytracer.h:440-454): builds scene_bvh and light_bvh with the
+ * reference's SAH sweep (bvh.h:268-393) on the host, flattens them into the HBM layouts of DESIGN.md and
+ * uploads everything to `device` (HIP ordinal). Caller keeps ownership of every pointer in `desc`. */
+int rt_create(const rt_scene_desc *desc, int device, rt_scene **out);
+void rt_destroy(rt_scene *scene);
+
+/* Replaces run_raytracer(scene, image) (raytracer.h:629-674). Blocking. fb_rgb: width*height*3 floats,
+ * row-major, y down, linear radiance = render_pixel(ctx,x,y) (raytracer.h:618-627). ray_depth == 0 is a
+ * silent no-op like raytracer.h:630-631. `stats` may be NULL. */
+int rt_render(rt_scene *scene, const rt_params *params, float *fb_rgb, rt_stats *stats);
+
+/* Closest-hit probe: cast `n` rays through the scene BVH exactly as cast_ray (raytracer.h:540-553) with
+ * min_dst = EPS. rays: 6*n floats (origin, dir). Outputs per ray: prim (original triangle index or
+ * 0xFFFFFFFF), and bct[3] = (b, c, t) of bvh.h:83-85. Used by the parity tests for bit-exact hit indices. */
+int rt_cast_rays(rt_scene *scene, const float *rays, uint32_t n, uint32_t *prim_out, float *bct_out);
+
+/* Light-pdf probe: bvh_mix_dist::pdf (raytracer.h:363-375) for n (origin, dir) pairs. */
+int rt_light_pdf(rt_scene *scene, const float *rays, uint32_t n, float *pdf_out);
+
+/* BVH introspection for parity tests: which = 0 scene_bvh, 1 light_bvh. Nodes are reported in the
+ * reference's own pre-order numbering (bvh.h:157-163, 351-363): 10 x u32-sized words per node
+ * {min.xyz, max.xyz (float bits), left, right, obj_begin, obj_end}; order = the BVH's object permutation
+ * (BVH::objects, bvh.h:166) as original triangle indices. Pass NULL buffers to query counts. */
+int rt_bvh_info(rt_scene *scene, int which, uint32_t *n_nodes, uint32_t *n_objects, uint32_t *root,
+                uint32_t *nodes_out /* 10*n_nodes */, uint32_t *order_out /* n_objects */);
+
+/* Film (image.h:49-82): ACES -> gamma 1/2.2 -> x255 -> clamp -> round -> u8. Host function; n pixels. */
+void rt_tonemap_rgb8(const float *rgb, size_t n_pixels, uint8_t *out_rgb8);
+
+const char *rt_last_error(void);
+uint32_t rt_abi_version(void);
+int rt_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

@@ -1,0 +1,166 @@
+/*
+ * rt_devspec.h — the parts of the sample loop whose arithmetic is DEFINED by this project rather than by the
+ * reference, written once so that the HIP kernels and the CPU oracle (oracle/rt_oracle.cpp, device-RNG mode)
+ * evaluate the very same IEEE-754 operation sequence:
+ *
+ *   1. rt_xoshiro  : xoshiro128++ (Blackman & Vigna 2019) per-lane generator, state derived by splitmix64 from
+ *                    (seed, pixel index, sample index). Replaces the reference's std::minstd_rand stream
+ *                    (raytracer.h:458,648) in RT_RNG_DEVICE mode; draw ORDER stays the reference's.
+ *   2. rt_minstd   : std::minstd_rand + the libstdc++-11 uniform_real<float> / uniform_int<int> algorithms
+ *                    (bits/random.tcc generate_canonical; bits/uniform_int_dist.h:277-330, the two-division
+ *                    "fallback" downscaling branch), used in RT_RNG_REFERENCE mode.
+ *   3. rt_sincos   : sin/cos of an angle in [0, 2*pi] evaluated in double precision (Cody-Waite quadrant
+ *                    reduction + Taylor/minimax polynomials) and rounded once to float. The reference calls glibc
+ *                    cosf/sinf (raytracer.h:104,158-159); glibc's results are not reproducible on a GPU, so
+ *                    device parity is defined against this function ("Hop 2").
+ *
+ * Only +,-,*,/ on float/double and integer ops are used; with floating-point contraction disabled
+ * (-ffp-contract=off, both compilers) the results are bit-identical on x86-64 and gfx950.
+ */
+#ifndef RT_DEVSPEC_H
+#define RT_DEVSPEC_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define RT_HD __host__ __device__ inline
+#else
+#define RT_HD static inline
+#endif
+
+/* ---------------------------------------------------------------- xoshiro128++ ---- */
+typedef struct rt_xoshiro {
+    uint32_t s[4];
+} rt_xoshiro;
+
+RT_HD uint64_t rt_splitmix64(uint64_t *x) {
+    uint64_t z = (*x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+RT_HD void rt_xoshiro_seed(rt_xoshiro *g, uint64_t seed, uint32_t pixel, uint32_t sample) {
+    uint64_t x = seed ^ (((uint64_t)pixel << 32) | (uint64_t)sample) * 0xD1342543DE82EF95ull;
+    uint64_t a = rt_splitmix64(&x);
+    uint64_t b = rt_splitmix64(&x);
+    g->s[0] = (uint32_t)a;
+    g->s[1] = (uint32_t)(a >> 32);
+    g->s[2] = (uint32_t)b;
+    g->s[3] = (uint32_t)(b >> 32);
+    if ((g->s[0] | g->s[1] | g->s[2] | g->s[3]) == 0u)
+        g->s[0] = 1u;
+}
+
+RT_HD uint32_t rt_rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+
+RT_HD uint32_t rt_xoshiro_next(rt_xoshiro *g) {
+    uint32_t r = rt_rotl32(g->s[0] + g->s[3], 7) + g->s[0];
+    uint32_t t = g->s[1] << 9;
+    g->s[2] ^= g->s[0];
+    g->s[3] ^= g->s[1];
+    g->s[1] ^= g->s[2];
+    g->s[0] ^= g->s[3];
+    g->s[2] ^= t;
+    g->s[3] = rt_rotl32(g->s[3], 11);
+    return r;
+}
+
+/* canonical float in [0,1): top 24 bits, exact */
+RT_HD float rt_xoshiro_canonical(rt_xoshiro *g) {
+    return (float)(rt_xoshiro_next(g) >> 8) * 5.9604644775390625e-08f; /* 2^-24 */
+}
+
+/* integer in [0, n): multiply-shift (deterministic; the tiny bias is irrelevant here) */
+RT_HD uint32_t rt_xoshiro_below(rt_xoshiro *g, uint32_t n) {
+    return (uint32_t)(((uint64_t)rt_xoshiro_next(g) * (uint64_t)n) >> 32);
+}
+
+/* ---------------------------------------------------------------- minstd_rand ---- */
+typedef struct rt_minstd {
+    uint32_t x;
+} rt_minstd;
+
+/* std::linear_congruential_engine<uint_fast32_t,48271,0,2147483647>::seed (bits/random.tcc): a seed that is
+ * 0 mod m becomes 1 — hence spans 0 and 1 share a stream. */
+RT_HD void rt_minstd_seed(rt_minstd *g, uint32_t seed) {
+    uint32_t v = seed % 2147483647u;
+    g->x = v == 0u ? 1u : v;
+}
+
+RT_HD uint32_t rt_minstd_next(rt_minstd *g) {
+    g->x = (uint32_t)(((uint64_t)g->x * 48271ull) % 2147483647ull);
+    return g->x;
+}
+
+/* generate_canonical<float,24>(minstd): m = 1 round; float(x - 1) / float(2147483646.0L) where the divisor
+ * rounds to 2^31; results >= 1 are replaced by nextafter(1,0). */
+RT_HD float rt_minstd_canonical(rt_minstd *g) {
+    float s = (float)(rt_minstd_next(g) - 1u);
+    float r = s / 2147483648.0f;
+    if (r >= 1.0f)
+        r = 0.99999994039535522461f;
+    return r;
+}
+
+/* uniform_int_distribution<int>(0, n-1)(minstd), n >= 1 */
+RT_HD uint32_t rt_minstd_below(rt_minstd *g, uint32_t n) {
+    const uint64_t urngrange = 2147483645ull; /* max - min */
+    const uint64_t uerange = (uint64_t)n;     /* urange + 1 */
+    const uint64_t scaling = urngrange / uerange;
+    const uint64_t past = uerange * scaling;
+    uint64_t ret;
+    do {
+        ret = (uint64_t)rt_minstd_next(g) - 1ull;
+    } while (ret >= past);
+    return (uint32_t)(ret / scaling);
+}
+
+/* ---------------------------------------------------------------- sin / cos ---- */
+/* Inputs are the sampled azimuths of raytracer.h:102 and :157, i.e. phi in [0, 2*pi] (float). Any finite
+ * input up to a few thousand is still reduced correctly; larger / non-finite inputs are not needed. */
+RT_HD void rt_sincos(float phi, float *s_out, float *c_out) {
+    const double x = (double)phi;
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632673412561417e+00; /* first 33 bits of pi/2 */
+    const double pio2_lo = 6.07710050650619224932e-11; /* pi/2 - pio2_hi */
+    /* k = nearest integer to x*2/pi for x >= 0 */
+    const double kd = (double)(int)(x * two_over_pi + 0.5);
+    const int k = (int)kd;
+    const double r = (x - kd * pio2_hi) - kd * pio2_lo;
+    const double z = r * r;
+    /* sin(r), |r| <= pi/4 + eps : r + r^3 * S(z) */
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double sp = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
+    const double sr = r + (r * z) * sp;
+    const double cp = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
+    const double cr = (1.0 - 0.5 * z) + (z * z) * cp;
+    double s, c;
+    switch (k & 3) {
+    case 0:
+        s = sr;
+        c = cr;
+        break;
+    case 1:
+        s = cr;
+        c = -sr;
+        break;
+    case 2:
+        s = -sr;
+        c = -cr;
+        break;
+    default:
+        s = -cr;
+        c = sr;
+        break;
+    }
+    *s_out = (float)s;
+    *c_out = (float)c;
+}
+
+#endif /* RT_DEVSPEC_H */

@@ -1,0 +1,37 @@
+/*
+ * rt_host.h — host-side callers of the hot path, C-ABI. These stay plain C++ on the CPU (BASELINE north_star):
+ * the glTF loader (reference src/scene.h:183-501), the film (src/image.h) and the PPM writer. They produce /
+ * consume exactly the POD arrays of rt_abi.h, so that tests and the CLI feed the HIP path and the CPU oracle
+ * from one loader.
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include "rt_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_loaded_scene rt_loaded_scene; /* owns the arrays an rt_scene_desc points into */
+
+/* parse_gltf_scene(path, aspect) (scene.h:183): glTF 2.0 with external .bin / image URIs, indexed triangle
+ * lists (mode 4) and strips (mode 5), node TRS + matrix, perspective camera, metallic-roughness materials,
+ * KHR_materials_emissive_strength. Quirks of the reference loader are kept (see DESIGN.md "loader quirks").
+ * Also sets bg_color = ENV_MAP_INTENSITY (main.cpp:28) and ray_depth = DEFAULT_RAY_DEPTH (scene.h:186). */
+int rt_gltf_load(const char *path, float aspect, rt_loaded_scene **out);
+const rt_scene_desc *rt_loaded_desc(const rt_loaded_scene *s);
+void rt_loaded_free(rt_loaded_scene *s);
+
+/* Image::write (image.h:34-38): binary PPM "P6\n<w> <h>\n255\n" + rgb8. Creates parent directories like
+ * main.cpp:40-41. */
+int rt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb8);
+
+/* PNG (8-bit, non-interlaced) -> RGBA8, the subset of stb_image the fixtures need. Caller frees with rt_free. */
+int rt_png_decode_file(const char *path, uint32_t *w, uint32_t *h, uint8_t **rgba8);
+void rt_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,143 @@
+// ref_probe.cpp — golden-vector harness. TEST INFRASTRUCTURE, built only in this container into oracle/_ref/.
+//
+// It #includes the reference's own headers from /root/reference/src (nothing is copied into the repo) and dumps
+// what the parity tests need below the PPM level (SURVEY 8c "golden vectors to manufacture" (2)):
+//
+//   ref_probe bvh      <gltf> <W> <H> <out.bin>            both BVHs: nodes (10 words each) + object order
+//   ref_probe cast     <gltf> <W> <H> <rays.bin> <out.bin> closest hits for explicit rays (prim, b, c, t)
+//   ref_probe primary  <gltf> <W> <H> <out.bin>            closest hits of pixel-centre rays gen_ray(camera,x,y)
+//   ref_probe lightpdf <gltf> <W> <H> <rays.bin> <out.bin> bvh_mix_dist::pdf for explicit (x, dir) pairs
+//   ref_probe scene    <gltf> <W> <H> <out.bin>            flattened scene.objects (positions/normals/uv/tangents)
+//
+// Binary formats are little-endian u32/f32 arrays described next to each writer.
+#define STB_IMAGE_IMPLEMENTATION
+#include "raytracer.h"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+static void put_u32(std::vector<uint32_t> &o, uint32_t v) { o.push_back(v); }
+static void put_f32(std::vector<uint32_t> &o, float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    o.push_back(u);
+}
+static std::vector<float> read_floats(const char *path) {
+    std::ifstream in(path, std::ios::binary | std::ios::ate);
+    size_t n = in.tellg();
+    in.seekg(0);
+    std::vector<float> v(n / 4);
+    in.read(reinterpret_cast<char *>(v.data()), n);
+    return v;
+}
+static void write_words(const char *path, const std::vector<uint32_t> &o) {
+    std::ofstream out(path, std::ios::binary);
+    out.write(reinterpret_cast<const char *>(o.data()), o.size() * 4);
+}
+
+int main(int argc, char **argv) {
+    if (argc < 6) {
+        std::fprintf(stderr, "usage: ref_probe <mode> <gltf> <W> <H> ...\n");
+        return 2;
+    }
+    std::string mode = argv[1];
+    unsigned width = std::strtol(argv[3], nullptr, 10);
+    unsigned height = std::strtol(argv[4], nullptr, 10);
+    Scene scene = parse_gltf_scene(std::filesystem::path(argv[2]), static_cast<float>(width) / height);
+    scene.bg_color = {ENV_MAP_INTENSITY, ENV_MAP_INTENSITY, ENV_MAP_INTENSITY};
+    scene.camera.width = width;
+    scene.camera.height = height;
+    scene.samples = 1;
+    RaytracerStaticContext ctx(scene);
+    const geometry::Object *base = scene.objects.data();
+    std::vector<uint32_t> out;
+
+    if (mode == "bvh") {
+        // [n_nodes, n_objs, root, nodes(10 each), order(n_objs)] x 2 (scene, light)
+        for (const BVH *b : {&ctx.scene_bvh, &ctx.light_bvh}) {
+            put_u32(out, b->nodes.size());
+            put_u32(out, b->objects.size());
+            put_u32(out, b->root);
+            for (auto &n : b->nodes) {
+                for (int k = 0; k < 3; ++k)
+                    put_f32(out, n.bounding_box.vmin().val[k]);
+                for (int k = 0; k < 3; ++k)
+                    put_f32(out, n.bounding_box.vmax().val[k]);
+                put_u32(out, n.left_child);
+                put_u32(out, n.right_child);
+                put_u32(out, n.obj_begin);
+                put_u32(out, n.obj_end);
+            }
+            for (auto *o : b->objects)
+                put_u32(out, (uint32_t)(o - base));
+        }
+        write_words(argv[5], out);
+    } else if (mode == "cast" || mode == "primary") {
+        std::vector<geometry::ray> rays;
+        const char *out_path;
+        if (mode == "cast") {
+            auto f = read_floats(argv[5]);
+            for (size_t i = 0; i + 5 < f.size(); i += 6)
+                rays.push_back({{f[i], f[i + 1], f[i + 2]}, {f[i + 3], f[i + 4], f[i + 5]}});
+            out_path = argv[6];
+        } else {
+            for (unsigned y = 0; y < height; ++y)
+                for (unsigned x = 0; x < width; ++x)
+                    rays.push_back(gen_ray(scene.camera, x, y));
+            out_path = argv[5];
+        }
+        // per ray: prim, b, c, t, then origin/dir (6 floats) so tests can re-cast the very same rays
+        for (auto &r : rays) {
+            intersection_res res;
+            if (ctx.scene_bvh.root != NO_CHILD)
+                res = ctx.scene_bvh.intersect_ray(r, EPS, ctx.scene_bvh.root);
+            put_u32(out, res.has_value() ? (uint32_t)(res->second - base) : 0xFFFFFFFFu);
+            put_f32(out, res.has_value() ? res->first.x() : 0.0f);
+            put_f32(out, res.has_value() ? res->first.y() : 0.0f);
+            put_f32(out, res.has_value() ? res->first.z() : 0.0f);
+            for (int k = 0; k < 3; ++k)
+                put_f32(out, r.start.val[k]);
+            for (int k = 0; k < 3; ++k)
+                put_f32(out, r.dir.val[k]);
+        }
+        write_words(out_path, out);
+    } else if (mode == "lightpdf") {
+        auto f = read_floats(argv[5]);
+        bvh_mix_dist dist{&ctx.light_bvh};
+        for (size_t i = 0; i + 5 < f.size(); i += 6) {
+            geometry::vec3 x{f[i], f[i + 1], f[i + 2]}, d{f[i + 3], f[i + 4], f[i + 5]};
+            float p = ctx.light_bvh.objects.empty() ? 0.0f : dist.pdf(x, {0, 0, 1}, d);
+            put_f32(out, p);
+        }
+        write_words(argv[6], out);
+    } else if (mode == "scene") {
+        // [n, then per object 9 pos + 9 normals + 6 uv + 9 tangents], camera (pos, right, up, forward, fov_x)
+        put_u32(out, scene.objects.size());
+        for (auto &o : scene.objects) {
+            for (auto &v : o.shape.vertices)
+                for (float c : v.val)
+                    put_f32(out, c);
+            for (auto &v : o.attrs.normals)
+                for (float c : v.val)
+                    put_f32(out, c);
+            for (auto &v : o.attrs.tex_coords)
+                for (float c : v.val)
+                    put_f32(out, c);
+            for (auto &v : o.attrs.tangents)
+                for (float c : v.val)
+                    put_f32(out, c);
+        }
+        for (auto *v : {&scene.camera.position, &scene.camera.right, &scene.camera.up, &scene.camera.forward})
+            for (float c : v->val)
+                put_f32(out, c);
+        put_f32(out, scene.camera.fov_x);
+        write_words(argv[5], out);
+    } else {
+        std::fprintf(stderr, "unknown mode %s\n", mode.c_str());
+        return 2;
+    }
+    return 0;
+}

@@ -1,0 +1,217 @@
+"""MI355X-native render loop for firelion9/raytracing-course-hw-public — Python host binding.
+
+The product is the C-ABI shared library `csrc/librt_amd.so` (include/rt_abi.h + include/rt_host.h): hand-written
+HIP kernels for gfx950 behind the seam the reference enters at `run_raytracer(scene, image)`
+(src/raytracer.h:629). This module is a thin ctypes mirror of that ABI for tests and bench.py; names follow
+the reference (`run_raytracer`, `parse_gltf_scene`, `Image.write`).
+
+There is NO CPU fallback: if the library is missing, or no GPU is present when a device entry point is called,
+the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import scenegen  # noqa: F401
+from ._ctypes_abi import (
+    ABI_PROTOTYPES,
+    ERROR_NAMES,
+    HOST_PROTOTYPES,
+    RT_FLAG_DEVICE_FB,
+    RT_OK,
+    RT_RNG_DEVICE,
+    RT_RNG_REFERENCE,
+    DescHolder,
+    RtParams,
+    RtSceneDesc,
+    RtStats,
+    bind,
+    c_u8_p,
+    desc_to_arrays,
+    fptr,
+    u8ptr,
+    u32ptr,
+)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librt_amd.so")
+_lib: Optional[C.CDLL] = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def lib() -> C.CDLL:
+    """Load csrc/librt_amd.so. Raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: the HIP library is not built; there is no CPU fallback. Run __graft_entry__.build().")
+        _lib = C.CDLL(LIB_PATH)
+        bind(_lib, ABI_PROTOTYPES)
+        bind(_lib, HOST_PROTOTYPES)
+    return _lib
+
+
+def _check(code: int) -> None:
+    if code != RT_OK:
+        raise RtError(code, lib().rt_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    return int(lib().rt_device_count())
+
+
+class LoadedScene:
+    """Result of parse_gltf_scene (scene.h:183) through the C++ host loader; owns the C-side arrays."""
+
+    def __init__(self, handle: C.c_void_p):
+        self._h = handle
+        self.desc: RtSceneDesc = lib().rt_loaded_desc(handle).contents
+
+    def arrays(self) -> dict:
+        return desc_to_arrays(self.desc)
+
+    def close(self) -> None:
+        if self._h:
+            lib().rt_loaded_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def parse_gltf_scene(path: str, aspect: float) -> LoadedScene:
+    h = C.c_void_p()
+    _check(lib().rt_gltf_load(os.fsencode(path), C.c_float(aspect), C.byref(h)))
+    return LoadedScene(h)
+
+
+def _as_desc(scene) -> Tuple[RtSceneDesc, object]:
+    if isinstance(scene, LoadedScene):
+        return scene.desc, scene
+    if isinstance(scene, RtSceneDesc):
+        return scene, None
+    holder = DescHolder(scene)
+    return holder.desc, holder
+
+
+class DeviceScene:
+    """Device-resident scene + both BVHs: the RaytracerStaticContext of raytracer.h:434-455, in HBM."""
+
+    def __init__(self, scene, device: int = 0):
+        desc, keep = _as_desc(scene)
+        self._keep = keep
+        self._h = C.c_void_p()
+        _check(lib().rt_create(C.byref(desc), int(device), C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run_raytracer(
+        self,
+        width: int,
+        height: int,
+        samples: int,
+        rng_mode: int = RT_RNG_DEVICE,
+        seed: int = 0,
+        shard_index: int = 0,
+        shard_count: int = 1,
+        shard_block: int = 0,
+        out: Optional[np.ndarray] = None,
+        device_fb: int = 0,
+    ):
+        """run_raytracer(scene, image) (raytracer.h:629): returns (linear float framebuffer (H,W,3), stats dict).
+        With `device_fb` (a device pointer) the framebuffer stays in HBM and None is returned for it."""
+        p = RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block, 0)
+        st = RtStats()
+        if device_fb:
+            p.flags = RT_FLAG_DEVICE_FB
+            _check(lib().rt_render(self._h, C.byref(p), C.c_void_p(device_fb), C.byref(st)))
+            return None, st.as_dict()
+        fb = out if out is not None else np.zeros((height, width, 3), dtype=np.float32)
+        assert fb.dtype == np.float32 and fb.flags["C_CONTIGUOUS"] and fb.size == width * height * 3
+        _check(lib().rt_render(self._h, C.byref(p), fb.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return fb, st.as_dict()
+
+    def cast_rays(self, rays: np.ndarray):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        prim = np.zeros(n, dtype=np.uint32)
+        bct = np.zeros((n, 3), dtype=np.float32)
+        _check(lib().rt_cast_rays(self._h, fptr(rays), n, u32ptr(prim), fptr(bct)))
+        return prim, bct
+
+    def light_pdf(self, rays: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        out = np.zeros(n, dtype=np.float32)
+        _check(lib().rt_light_pdf(self._h, fptr(rays), n, fptr(out)))
+        return out
+
+    def bvh_info(self, which: int):
+        nn, no, root = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib().rt_bvh_info(self._h, which, C.byref(nn), C.byref(no), C.byref(root), None, None))
+        nodes = np.zeros((nn.value, 10), dtype=np.uint32)
+        order = np.zeros(no.value, dtype=np.uint32)
+        _check(lib().rt_bvh_info(self._h, which, C.byref(nn), C.byref(no), C.byref(root), u32ptr(nodes), u32ptr(order)))
+        return {"root": root.value, "nodes": nodes, "order": order}
+
+
+def tonemap(fb: np.ndarray) -> np.ndarray:
+    """Image::set_pixel's convert_color (image.h:40-42, 79-82) over a whole linear framebuffer -> (H,W,3) u8."""
+    fb = np.ascontiguousarray(fb, dtype=np.float32)
+    out = np.zeros(fb.shape, dtype=np.uint8)
+    lib().rt_tonemap_rgb8(fptr(fb), fb.size // 3, u8ptr(out))
+    return out
+
+
+def write_ppm(path: str, rgb8: np.ndarray) -> None:
+    """Image::write (image.h:34-38)."""
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _ = rgb8.shape
+    _check(lib().rt_write_ppm(os.fsencode(path), w, h, u8ptr(rgb8)))
+
+
+def png_decode(path: str) -> np.ndarray:
+    w, h = C.c_uint32(), C.c_uint32()
+    p = c_u8_p()
+    _check(lib().rt_png_decode_file(os.fsencode(path), C.byref(w), C.byref(h), C.byref(p)))
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib().rt_free(p)
+
+
+__all__ = [
+    "DeviceScene",
+    "LoadedScene",
+    "RT_RNG_DEVICE",
+    "RT_RNG_REFERENCE",
+    "RtError",
+    "device_count",
+    "lib",
+    "parse_gltf_scene",
+    "png_decode",
+    "scenegen",
+    "tonemap",
+    "write_ppm",
+]
