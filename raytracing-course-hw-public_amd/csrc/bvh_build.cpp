@@ -1,0 +1,221 @@
+// bvh_build.cpp — host SAH sweep builder that reproduces the reference's BVH topology exactly, then flattens it.
+//
+// Follows src/bvh.h:262-393: longest-axis choice (272-276), std::sort by centroid (278), prefix/suffix "surface
+// area" sweep (280-297) using aabb::surface_area() = 2*dot(diag, diag.yxz()) (geometry.h:419-421; note this is
+// 2*(dx*dy + dy*dx + dz*dz), kept as is), the score with its pref[i+1] index (302-310), leaf rules (343-346),
+// depth cap 64 (371), pre-order node numbering (351-363).
+//
+// Identical topology needs (a) the same float expressions without contraction and (b) the same permutation out of
+// std::sort for equal keys. (b) holds because introsort's decisions depend only on comparator outcomes and element
+// positions: we sort {key, index} pairs with `a.key < b.key`, the reference sorts Object pointers with the same
+// predicate on the same initial order, both with this toolchain's libstdc++.
+//
+// This builder stays on the host (SURVEY 8f-1 lists a device builder as a "next" row); it is not part of the timed
+// render loop, exactly as the reference's BVH builds happen once before the pixel loop (raytracer.h:633).
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace rt {
+namespace {
+
+inline float fmin_ref(float a, float b) { return (b < a) ? b : a; } // std::min(a, b)
+inline float fmax_ref(float a, float b) { return (a < b) ? b : a; } // std::max(a, b)
+
+struct Box {
+    float lo[3] = {INFINITY, INFINITY, INFINITY};
+    float hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    void extend_point(const float *p) { // aabb::extend(vec3) geometry.h:393-396
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fmin_ref(lo[k], p[k]);
+            hi[k] = fmax_ref(hi[k], p[k]);
+        }
+    }
+    void extend(const Box &b) { // geometry.h:398-401
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fmin_ref(lo[k], b.lo[k]);
+            hi[k] = fmax_ref(hi[k], b.hi[k]);
+        }
+    }
+    float surface_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return 2 * (dx * dy + dy * dx + dz * dz);
+    }
+};
+
+struct Keyed {
+    float key;
+    uint32_t idx;
+};
+
+struct Builder {
+    const float *pos;
+    std::vector<Box> tri_box;      // per original triangle
+    std::vector<float> center[3];  // triangle::center() geometry.h:485-487
+    std::vector<HostNode> nodes;
+    std::vector<float> pref, suf;
+    std::vector<Keyed> scratch;
+
+    Box bounds_of(const uint32_t *objs, size_t n) const { // bvh.h:315-321
+        Box r;
+        for (size_t i = 0; i < n; ++i)
+            r.extend(tri_box[objs[i]]);
+        return r;
+    }
+
+    size_t split(uint32_t *objs, size_t n, const Box &box) { // bvh.h:268-313
+        float dx = box.hi[0] - box.lo[0], dy = box.hi[1] - box.lo[1], dz = box.hi[2] - box.lo[2];
+        int axis = (dx >= dy && dx >= dz) ? 0 : (dy >= dz ? 1 : 2);
+        const float *keys = center[axis].data();
+        scratch.resize(n);
+        for (size_t i = 0; i < n; ++i)
+            scratch[i] = {keys[objs[i]], objs[i]};
+        std::sort(scratch.begin(), scratch.end(), [](const Keyed &l, const Keyed &r) { return l.key < r.key; });
+        for (size_t i = 0; i < n; ++i)
+            objs[i] = scratch[i].idx;
+
+        pref.clear();
+        suf.clear();
+        Box acc;
+        pref.push_back(acc.surface_area());
+        for (size_t i = 0; i < n; ++i) {
+            acc.extend(tri_box[objs[i]]);
+            pref.push_back(acc.surface_area());
+        }
+        acc = Box();
+        suf.push_back(acc.surface_area());
+        for (size_t i = n; i-- > 0;) {
+            acc.extend(tri_box[objs[i]]);
+            suf.push_back(acc.surface_area());
+        }
+        size_t best = n; // objs.end(): "no split"
+        float best_score = n * acc.surface_area();
+        for (int i = 1; i < (int)n; ++i) {
+            float score = i * pref[i + 1] + (n - i) * suf[n - i];
+            if (score < best_score) {
+                best_score = score;
+                best = (size_t)i;
+            }
+        }
+        return best;
+    }
+
+    uint32_t build(uint32_t offset, uint32_t *objs, size_t n, const Box &box, uint32_t min_node_size, uint32_t depth_left) { // bvh.h:323-366
+        auto leaf = [&]() {
+            HostNode nd;
+            std::memcpy(nd.lo, box.lo, sizeof(nd.lo));
+            std::memcpy(nd.hi, box.hi, sizeof(nd.hi));
+            nd.left = nd.right = RT_NONE;
+            nd.obj_begin = offset;
+            nd.obj_end = (uint32_t)(offset + n);
+            nodes.push_back(nd);
+            return (uint32_t)(nodes.size() - 1);
+        };
+        if (depth_left == 0)
+            return leaf();
+        size_t mid = split(objs, n, box);
+        size_t nl = mid, nr = n - mid;
+        if (nl == 0 || nr == 0 || (nl < min_node_size && nr < min_node_size))
+            return leaf();
+        uint32_t idx = (uint32_t)nodes.size();
+        HostNode nd;
+        std::memcpy(nd.lo, box.lo, sizeof(nd.lo));
+        std::memcpy(nd.hi, box.hi, sizeof(nd.hi));
+        nd.left = nd.right = RT_NONE;
+        nd.obj_begin = nd.obj_end = 0;
+        nodes.push_back(nd);
+        uint32_t l = build(offset, objs, nl, bounds_of(objs, nl), min_node_size, depth_left - 1);
+        uint32_t r = build((uint32_t)(offset + nl), objs + nl, nr, bounds_of(objs + nl, nr), min_node_size, depth_left - 1);
+        nodes[idx].left = l;
+        nodes[idx].right = r;
+        return idx;
+    }
+};
+
+} // namespace
+
+HostBvh build_bvh(const float *positions, uint32_t n_total, const std::vector<uint32_t> &subset) {
+    HostBvh out;
+    if (n_total == 0) { // bvh.h:373-376
+        out.root = RT_NONE;
+        return out;
+    }
+    Builder b;
+    b.pos = positions;
+    b.tri_box.resize(n_total);
+    for (int k = 0; k < 3; ++k)
+        b.center[k].resize(n_total);
+    for (uint32_t t : subset) {
+        const float *p = positions + 9 * (size_t)t;
+        Box bx; // triangle::bounding_box geometry.h:489-495
+        bx.extend_point(p);
+        bx.extend_point(p + 3);
+        bx.extend_point(p + 6);
+        b.tri_box[t] = bx;
+        for (int k = 0; k < 3; ++k)
+            b.center[k][t] = (p[k] + p[3 + k] + p[6 + k]) / 3;
+    }
+    out.order = subset;
+    Box root_box = b.bounds_of(out.order.data(), out.order.size());
+    out.root = b.build(0, out.order.data(), out.order.size(), root_box, 4, 64);
+    out.nodes = std::move(b.nodes);
+    return out;
+}
+
+FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions) {
+    FlatBvh f;
+    if (bvh.root == RT_NONE)
+        return f;
+    // sorted triangle records
+    f.tris.resize(bvh.order.size());
+    for (size_t k = 0; k < bvh.order.size(); ++k) {
+        const float *p = positions + 9 * (size_t)bvh.order[k];
+        DevTri &t = f.tris[k];
+        for (int c = 0; c < 3; ++c) {
+            t.a[c] = p[c];
+            t.v[c] = p[3 + c] - p[c];
+            t.u[c] = p[6 + c] - p[c];
+        }
+        t.prim = bvh.order[k];
+        t.flags = 0;
+        t.pad = 0;
+    }
+    // inner nodes get device indices in pre-order among inner nodes
+    std::vector<uint32_t> dev_index(bvh.nodes.size(), RT_NONE);
+    uint32_t n_inner = 0;
+    for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+        const HostNode &nd = bvh.nodes[i];
+        if (nd.left != RT_NONE || nd.right != RT_NONE)
+            dev_index[i] = n_inner++;
+        else if (nd.obj_end > nd.obj_begin)
+            f.tris[nd.obj_end - 1].flags |= 1u;
+    }
+    auto ref_of = [&](uint32_t node) -> uint32_t {
+        const HostNode &nd = bvh.nodes[node];
+        if (dev_index[node] != RT_NONE)
+            return dev_index[node];
+        return RT_LEAF_FLAG | nd.obj_begin;
+    };
+    f.nodes.resize(n_inner);
+    for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+        if (dev_index[i] == RT_NONE)
+            continue;
+        const HostNode &nd = bvh.nodes[i];
+        DevNode &d = f.nodes[dev_index[i]];
+        const HostNode &l = bvh.nodes[nd.left];
+        const HostNode &r = bvh.nodes[nd.right];
+        std::memcpy(d.lmin, l.lo, 12);
+        std::memcpy(d.lmax, l.hi, 12);
+        std::memcpy(d.rmin, r.lo, 12);
+        std::memcpy(d.rmax, r.hi, 12);
+        d.left = ref_of(nd.left);
+        d.right = ref_of(nd.right);
+        d.pad[0] = d.pad[1] = 0;
+    }
+    f.root = ref_of(bvh.root);
+    return f;
+}
+
+} // namespace rt

@@ -1,0 +1,65 @@
+// main.cpp — host driver behind the reference's CLI:  run.sh <scene.gltf> <W> <H> <SPP> <out.ppm>
+// Restates src/main.cpp:16-49: parse 5 positional arguments, load the scene, render, tone-map, write the PPM.
+// The only change of substance is line 37 of the reference: run_raytracer(scene, img) becomes
+// rt_create + rt_render through the C ABI (include/rt_abi.h); the film (image.h) is applied afterwards.
+// Optional environment: RT_DEVICE (HIP ordinal, default 0), RT_RNG_MODE (device|reference), RT_SEED.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../../include/rt_abi.h"
+#include "../../../include/rt_host.h"
+
+static int die(const char *what) {
+    std::cerr << what << ": " << rt_last_error() << std::endl; // main.cpp:46-49
+    return EXIT_FAILURE;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 6) {
+        std::cerr << "Too few arguments: expected 6, got " << argc - 1 << std::endl; // main.cpp:17-21 (sic)
+        return EXIT_FAILURE;
+    }
+    unsigned width = std::strtol(argv[2], nullptr, 10);
+    unsigned height = std::strtol(argv[3], nullptr, 10);
+    unsigned samples = std::strtol(argv[4], nullptr, 10);
+    if ((int)width <= 0 || (int)height <= 0) { // Image ctor image.h:25-29
+        std::cerr << "Illegal image size" << (int)width << "x" << (int)height << std::endl;
+        return EXIT_FAILURE;
+    }
+    rt_loaded_scene *loaded = nullptr;
+    if (rt_gltf_load(argv[1], static_cast<float>(width) / height, &loaded) != RT_OK)
+        return die("load");
+    const char *dev_env = std::getenv("RT_DEVICE");
+    rt_scene *scene = nullptr;
+    if (rt_create(rt_loaded_desc(loaded), dev_env ? std::atoi(dev_env) : 0, &scene) != RT_OK) {
+        rt_loaded_free(loaded);
+        return die("rt_create");
+    }
+    rt_params p{};
+    p.width = width;
+    p.height = height;
+    p.samples = samples;
+    const char *mode = std::getenv("RT_RNG_MODE");
+    p.rng_mode = (mode && !std::strcmp(mode, "reference")) ? RT_RNG_REFERENCE : RT_RNG_DEVICE;
+    const char *seed = std::getenv("RT_SEED");
+    p.seed = seed ? std::strtoull(seed, nullptr, 0) : 0;
+    std::vector<float> fb((size_t)width * height * 3, 0.0f);
+    rt_stats st{};
+    int rc = rt_render(scene, &p, fb.data(), &st);
+    rt_destroy(scene);
+    rt_loaded_free(loaded);
+    if (rc != RT_OK)
+        return die("rt_render");
+    std::vector<uint8_t> rgb8(fb.size());
+    rt_tonemap_rgb8(fb.data(), (size_t)width * height, rgb8.data());
+    if (rt_write_ppm(argv[5], width, height, rgb8.data()) != RT_OK)
+        return die("write");
+    if (std::getenv("RT_VERBOSE"))
+        std::fprintf(stderr, "samples=%llu kernel_ms=%.3f Msamples/s=%.3f\n", (unsigned long long)st.samples, st.kernel_ms,
+                     st.kernel_ms > 0 ? st.samples / st.kernel_ms / 1e3 : 0.0);
+    return EXIT_SUCCESS;
+}

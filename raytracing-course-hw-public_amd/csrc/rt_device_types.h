@@ -1,0 +1,108 @@
+// rt_device_types.h — HBM data layout of the render loop (see DESIGN.md "Data layout in HBM").
+//
+// The reference walks `std::vector<BVHNode>` (40 B: a node's OWN box + links, bvh.h:157-163) and, per triangle,
+// chases a `const Object*` into 208-byte AoS objects of which 36 bytes are used (geometry.h:639-643). Here:
+//   * DevNode  (64 B, one per INNER node): BOTH children's boxes + child refs -> one 64-byte fetch per visited
+//     inner node instead of two dependent 40-byte ones; leaves have no node record at all.
+//   * DevTri   (48 B, in BVH leaf order): a, b-a, c-a (exactly the operands of bvh.h:40-43), the original
+//     primitive index and an end-of-leaf flag; three aligned 16-byte loads, contiguous within a leaf.
+//   * DevAttr  (128 B, same order): what to_intersection_info (bvh.h:80-121) reads on a shaded hit.
+//   * DevMaterial (64 B) + texture table + RGBA8 texel pool + two 256-entry float tables.
+// Every lane of a wavefront follows its own ray, so accesses are per-lane gathers: records are sized and aligned
+// so that one gather touches the minimum number of 64/128-byte lines.
+#pragma once
+#include <stdint.h>
+
+#define RT_NONE 0xFFFFFFFFu
+#define RT_LEAF_FLAG 0x80000000u
+#define RT_MAX_STACK 64      /* bvh.h:371 max_depth = 64 -> at most 64 deferred siblings */
+#define RT_MAX_RAY_DEPTH 32u /* reference uses 8 (config.h:17) */
+#define RT_SPAN 256u         /* config.h:13 */
+
+struct alignas(16) DevNode {
+    float lmin[3], lmax[3]; // bounding box of the left child (bvh.h:208)
+    float rmin[3], rmax[3]; // bounding box of the right child (bvh.h:212)
+    uint32_t left, right;   // inner: index into DevNode[]; leaf: RT_LEAF_FLAG | first DevTri index
+    uint32_t pad[2];
+};
+static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
+
+struct alignas(16) DevTri {
+    float a[3];
+    float v[3]; // b - a   (triangle::v geometry.h:473)
+    float u[3]; // c - a   (triangle::u geometry.h:475)
+    uint32_t prim;  // original triangle index (scene.objects position)
+    uint32_t flags; // bit0: last triangle of its leaf
+    uint32_t pad;
+};
+static_assert(sizeof(DevTri) == 48, "DevTri must be 48 bytes");
+
+struct alignas(16) DevAttr {
+    float n[9];  // attrs.normals
+    float tg[9]; // attrs.tangents
+    float uv[6]; // attrs.tex_coords
+    float gn[3]; // base_normal() = norm(crs(v,u)) (geometry.h:648-650), precomputed with the same float ops
+    uint32_t material;
+    uint32_t pad[4];
+};
+static_assert(sizeof(DevAttr) == 128, "DevAttr must be 128 bytes");
+
+struct alignas(16) DevLightAux { // per light triangle (light-BVH order): triangle::normal(), triangle::square()
+    float normal[3];
+    float area;
+};
+
+struct alignas(16) DevMaterial {
+    float color[4];
+    float emission[3];
+    float roughness;
+    float metallic;
+    float ior;
+    int32_t color_tex, emissive_tex, mr_tex, normal_tex; // -1 = WHITE_TEXTURE / NORMAL_UP
+    uint32_t pad[2];
+};
+static_assert(sizeof(DevMaterial) == 64, "DevMaterial must be 64 bytes");
+
+struct DevTexture {
+    uint32_t width, height;
+    uint32_t offset; // first texel in the pool
+    uint32_t count;  // width*height (== 1 -> Texture::sample's 1x1 fast path, geometry.h:548-550)
+};
+
+struct DevBvh {
+    const DevNode *nodes;
+    const DevTri *tris;
+    uint32_t root;   // RT_NONE (no objects at all), inner index, or RT_LEAF_FLAG|0
+    uint32_t n_tris; // BVH::objects.size()
+};
+
+struct DevScene {
+    DevBvh scene;
+    DevBvh lights;
+    const DevAttr *attrs;          // scene-BVH order
+    const DevLightAux *light_aux;  // light-BVH order
+    const DevMaterial *materials;
+    const DevTexture *textures;
+    const uint32_t *texels;        // RGBA8, r in the low byte
+    const float *lut_linear;       // k / 255.0f            (geometry.h:593-594)
+    const float *lut_gamma;        // powf(k / 255.0f, 2.2f) (geometry.h:525-527, 616, 620)
+    float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
+    float bg[3];
+    uint32_t ray_depth;
+};
+
+struct DevStats { // device-side counters, see rt_stats in include/rt_abi.h
+    unsigned long long samples, casts, nodes, box_tests, tri_tests, shaded, lq, lnodes, lbox, ltri, lhits, texels;
+};
+
+struct RenderLaunch {
+    uint32_t width, height, samples, rng_mode;
+    uint64_t seed;
+    uint32_t shard_index, shard_count, shard_block; // normalised: count >= 1, block >= 1
+    uint32_t n_items;      // work items of THIS shard (pixels in device mode, 256-pixel spans in reference mode)
+    uint32_t items_per_block; // work items per shard block
+    float tan_x, tan_y;    // tan(fov_x/2), tan(fov_y/2) hoisted from gen_ray (raytracer.h:531-535)
+    float *fb;             // width*height*3, device
+    uint32_t *counter;     // work-item ticket
+    DevStats *stats;       // may be null
+};

@@ -1,0 +1,445 @@
+// rt_scene.cpp — C-ABI entry points of include/rt_abi.h: scene residency + launches.
+//
+// rt_create  replaces RaytracerStaticContext(scene) (src/raytracer.h:440-454): two host BVH builds in the
+//            reference topology, flattening, upload to HBM.
+// rt_render  replaces run_raytracer(scene, image) (src/raytracer.h:629-674): one persistent-wavefront launch.
+// There is no CPU fallback anywhere in this file: without a HIP device every device entry point fails.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "bvh_build.h"
+#include "rt_device_types.h"
+#include "rt_error.h"
+#include "rt_kernels.h"
+
+namespace {
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return rt::fail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : (e_ == hipErrorNoDevice ? RT_ERR_NO_DEVICE : RT_ERR_HIP), \
+                            std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+    } while (0)
+
+template <class T> int upload(const std::vector<T> &v, const T **out, std::vector<void *> &owned) {
+    *out = nullptr;
+    if (v.empty())
+        return RT_OK;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
+    owned.push_back(p);
+    HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(p);
+    return RT_OK;
+}
+
+struct V3h {
+    float x, y, z;
+};
+inline V3h cross_h(V3h a, V3h b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float len_h(V3h a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+
+} // namespace
+
+struct rt_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevScene dev{};
+    rt_camera cam{};
+    std::vector<void *> owned;
+    rt::HostBvh host_bvh[2];
+    uint32_t *d_counter = nullptr;
+    DevStats *d_stats = nullptr;
+    float *d_fb = nullptr;
+    size_t fb_capacity = 0; // floats
+    int num_cus = 0;
+    int blocks_per_cu = 4;
+    ~rt_scene() {
+        (void)hipSetDevice(device);
+        for (void *p : owned)
+            (void)hipFree(p);
+        if (d_fb)
+            (void)hipFree(d_fb);
+        if (ev0)
+            (void)hipEventDestroy(ev0);
+        if (ev1)
+            (void)hipEventDestroy(ev1);
+        if (stream)
+            (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return rt::fail(RT_ERR_NO_DEVICE, "rt_create: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_create: device ordinal out of range");
+    s->device = device;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    s->num_cus = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+
+    const uint32_t n = d->n_triangles;
+    for (uint32_t i = 0; i < n; ++i)
+        if (d->material_ids[i] >= d->n_materials)
+            return rt::fail(RT_ERR_INVALID_ARG, "rt_create: material id out of range");
+    auto tex_ok = [&](int32_t t) { return t < 0 || (uint32_t)t < d->n_textures; };
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const rt_material_desc &m = d->materials[i];
+        if (!tex_ok(m.color_tex) || !tex_ok(m.emissive_tex) || !tex_ok(m.metallic_roughness_tex) || !tex_ok(m.normal_tex))
+            return rt::fail(RT_ERR_INVALID_ARG, "rt_create: texture index out of range");
+    }
+
+    // ---- RaytracerStaticContext: scene_bvh over everything, light_bvh over emission != 0 (raytracer.h:441-447)
+    std::vector<uint32_t> all(n), lights;
+    for (uint32_t i = 0; i < n; ++i) {
+        all[i] = i;
+        const float *e = d->materials[d->material_ids[i]].emission;
+        if (!((e[0] == 0) & (e[1] == 0) & (e[2] == 0)))
+            lights.push_back(i);
+    }
+    s->host_bvh[0] = rt::build_bvh(d->positions, n, all);
+    s->host_bvh[1] = rt::build_bvh(d->positions, n, lights);
+    rt::FlatBvh flat[2] = {rt::flatten_bvh(s->host_bvh[0], d->positions), rt::flatten_bvh(s->host_bvh[1], d->positions)};
+
+    // ---- shading records in scene-BVH order
+    std::vector<DevAttr> attrs(flat[0].tris.size());
+    for (size_t k = 0; k < attrs.size(); ++k) {
+        const uint32_t t = flat[0].tris[k].prim;
+        DevAttr &a = attrs[k];
+        std::memset(&a, 0, sizeof(a));
+        std::memcpy(a.n, d->normals + 9 * (size_t)t, 36);
+        std::memcpy(a.tg, d->tangents + 9 * (size_t)t, 36);
+        std::memcpy(a.uv, d->texcoords + 6 * (size_t)t, 24);
+        const DevTri &tr = flat[0].tris[k];
+        V3h c = cross_h({tr.v[0], tr.v[1], tr.v[2]}, {tr.u[0], tr.u[1], tr.u[2]}); // triangle::normal geometry.h:477-479
+        float l = len_h(c);
+        a.gn[0] = c.x / l;
+        a.gn[1] = c.y / l;
+        a.gn[2] = c.z / l;
+        a.material = d->material_ids[t];
+    }
+    std::vector<DevLightAux> laux(flat[1].tris.size());
+    for (size_t k = 0; k < laux.size(); ++k) {
+        const DevTri &tr = flat[1].tris[k];
+        V3h c = cross_h({tr.v[0], tr.v[1], tr.v[2]}, {tr.u[0], tr.u[1], tr.u[2]});
+        float l = len_h(c);
+        laux[k].normal[0] = c.x / l;
+        laux[k].normal[1] = c.y / l;
+        laux[k].normal[2] = c.z / l;
+        laux[k].area = l / 2; // triangle::square geometry.h:481-483
+    }
+    std::vector<DevMaterial> mats(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const rt_material_desc &m = d->materials[i];
+        DevMaterial &o = mats[i];
+        std::memset(&o, 0, sizeof(o));
+        std::memcpy(o.color, m.color, 16);
+        std::memcpy(o.emission, m.emission, 12);
+        o.roughness = m.roughness;
+        o.metallic = m.metallic;
+        o.ior = m.ior;
+        o.color_tex = m.color_tex;
+        o.emissive_tex = m.emissive_tex;
+        o.mr_tex = m.metallic_roughness_tex;
+        o.normal_tex = m.normal_tex;
+    }
+    std::vector<DevTexture> texs(d->n_textures);
+    std::vector<uint32_t> pool;
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const rt_texture_desc &t = d->textures[i];
+        if (t.width == 0 || t.height == 0 || !t.rgba8)
+            return rt::fail(RT_ERR_INVALID_ARG, "rt_create: empty texture");
+        texs[i] = {t.width, t.height, (uint32_t)pool.size(), t.width * t.height};
+        size_t cnt = (size_t)t.width * t.height;
+        size_t base = pool.size();
+        pool.resize(base + cnt);
+        std::memcpy(pool.data() + base, t.rgba8, cnt * 4);
+    }
+    std::vector<float> lut_lin(256), lut_gam(256);
+    for (int k = 0; k < 256; ++k) {
+        lut_lin[k] = k / 255.0f;               // Texture::load_img geometry.h:593-594
+        lut_gam[k] = std::pow(lut_lin[k], 2.2f); // rgba_apply_gamma geometry.h:525-527 (float powf)
+    }
+
+    DevScene &D = s->dev;
+    int rc;
+    for (int w = 0; w < 2; ++w) {
+        DevBvh &b = w == 0 ? D.scene : D.lights;
+        if ((rc = upload(flat[w].nodes, &b.nodes, s->owned)) != RT_OK)
+            return rc;
+        if ((rc = upload(flat[w].tris, &b.tris, s->owned)) != RT_OK)
+            return rc;
+        b.root = flat[w].root;
+        b.n_tris = (uint32_t)flat[w].tris.size();
+    }
+    if ((rc = upload(attrs, &D.attrs, s->owned)) != RT_OK)
+        return rc;
+    if ((rc = upload(laux, &D.light_aux, s->owned)) != RT_OK)
+        return rc;
+    if ((rc = upload(mats, &D.materials, s->owned)) != RT_OK)
+        return rc;
+    if ((rc = upload(texs, &D.textures, s->owned)) != RT_OK)
+        return rc;
+    if ((rc = upload(pool, &D.texels, s->owned)) != RT_OK)
+        return rc;
+    if ((rc = upload(lut_lin, &D.lut_linear, s->owned)) != RT_OK)
+        return rc;
+    if ((rc = upload(lut_gam, &D.lut_gamma, s->owned)) != RT_OK)
+        return rc;
+    std::memcpy(D.cam_pos, d->camera.position, 12);
+    std::memcpy(D.cam_right, d->camera.right, 12);
+    std::memcpy(D.cam_up, d->camera.up, 12);
+    std::memcpy(D.cam_fwd, d->camera.forward, 12);
+    std::memcpy(D.bg, d->bg_color, 12);
+    D.ray_depth = d->ray_depth;
+    s->cam = d->camera;
+
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, sizeof(uint32_t) * 64));
+    s->owned.push_back(p);
+    s->d_counter = static_cast<uint32_t *>(p);
+    HIP_TRY(hipMalloc(&p, sizeof(DevStats)));
+    s->owned.push_back(p);
+    s->d_stats = static_cast<DevStats *>(p);
+    return RT_OK;
+}
+
+extern "C" int rt_create(const rt_scene_desc *desc, int device, rt_scene **out) {
+    if (!desc || !out)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_create: null argument");
+    if (desc->abi_version != RT_ABI_VERSION)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_create: ABI version mismatch");
+    if (desc->ray_depth > RT_MAX_RAY_DEPTH)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_create: ray_depth above RT_MAX_RAY_DEPTH (32)");
+    if (desc->n_triangles && (!desc->positions || !desc->normals || !desc->texcoords || !desc->tangents || !desc->material_ids || !desc->materials))
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_create: null geometry array");
+    if (desc->n_triangles >= 0x7FFFFFF0u)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_create: too many triangles");
+    rt_scene *s = new rt_scene();
+    int rc = create_impl(desc, device, s);
+    if (rc != RT_OK) {
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return RT_OK;
+}
+
+extern "C" void rt_destroy(rt_scene *scene) { delete scene; }
+
+extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stats *stats) {
+    if (!s || !p || !fb_rgb)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
+    if (p->width == 0 || p->height == 0 || (uint64_t)p->width * p->height >= 0x7FFFFFFFull)
+        return rt::fail(RT_ERR_INVALID_ARG, "Illegal image size" + std::to_string(p->width) + "x" + std::to_string(p->height)); // image.h:26
+    if (p->rng_mode != RT_RNG_DEVICE && p->rng_mode != RT_RNG_REFERENCE)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_render: unknown rng_mode");
+    if (p->samples == 0)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_render: samples must be >= 1");
+    auto wall0 = std::chrono::steady_clock::now();
+    if (stats)
+        std::memset(stats, 0, sizeof(*stats));
+    if (s->dev.ray_depth == 0) // raytracer.h:630-631
+        return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+
+    const uint32_t n_pix = p->width * p->height;
+    RenderLaunch L{};
+    L.width = p->width;
+    L.height = p->height;
+    L.samples = p->samples;
+    L.rng_mode = p->rng_mode;
+    L.seed = p->seed;
+    L.shard_count = p->shard_count ? p->shard_count : 1;
+    L.shard_index = p->shard_index;
+    if (L.shard_index >= L.shard_count)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_render: shard_index >= shard_count");
+    const uint32_t unit = p->rng_mode == RT_RNG_REFERENCE ? RT_SPAN : 1u;
+    uint32_t block = p->shard_block ? p->shard_block : (L.shard_count > 1 ? RT_SPAN * 8u : n_pix);
+    if (L.shard_count == 1)
+        block = ((n_pix + unit - 1) / unit) * unit; // one block holding everything
+    if (block % unit != 0)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_render: shard_block must be a multiple of 256 in reference RNG mode");
+    L.shard_block = block;
+    L.items_per_block = block / unit;
+    // work items of this shard: blocks b = shard_index, shard_index + count, ... below ceil(n_pix / block)
+    const uint64_t n_blocks = ((uint64_t)n_pix + block - 1) / block;
+    uint64_t items = 0;
+    for (uint64_t b = L.shard_index; b < n_blocks; b += L.shard_count) {
+        uint64_t first = b * block, last = std::min<uint64_t>(first + block, n_pix);
+        items += (last - first + unit - 1) / unit;
+    }
+    L.n_items = (uint32_t)items;
+    // gen_ray's tan terms (raytracer.h:531-535) and Camera::fov_y (scene.h:69-71), float overloads
+    L.tan_x = std::tan(s->cam.fov_x / 2);
+    const float fov_y = std::atan(std::tan(s->cam.fov_x / 2) * p->height / p->width) * 2;
+    L.tan_y = std::tan(fov_y / 2);
+
+    const bool device_fb = (p->flags & RT_FLAG_DEVICE_FB) != 0;
+    const size_t fb_floats = (size_t)n_pix * 3;
+    float *d_fb = fb_rgb;
+    if (!device_fb) {
+        if (s->fb_capacity < fb_floats) {
+            if (s->d_fb)
+                (void)hipFree(s->d_fb);
+            s->d_fb = nullptr;
+            s->fb_capacity = 0;
+            void *q = nullptr;
+            HIP_TRY(hipMalloc(&q, fb_floats * sizeof(float)));
+            s->d_fb = static_cast<float *>(q);
+            s->fb_capacity = fb_floats;
+        }
+        d_fb = s->d_fb;
+    }
+    L.fb = d_fb;
+    L.counter = s->d_counter;
+    L.stats = stats ? s->d_stats : nullptr;
+    HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), s->stream));
+    if (stats)
+        HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DevStats), s->stream));
+
+    int blocks = (int)std::min<uint64_t>((items + 255) / 256, (uint64_t)s->num_cus * s->blocks_per_cu);
+    if (blocks < 1)
+        blocks = 1;
+    if (L.n_items > 0) {
+        HIP_TRY(hipEventRecord(s->ev0, s->stream));
+        HIP_TRY(rt::launch_render(s->dev, L, stats != nullptr, blocks, s->stream));
+        HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    float ms = 0;
+    if (L.n_items > 0)
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+
+    if (!device_fb && L.n_items > 0) {
+        if (L.shard_count == 1) {
+            HIP_TRY(hipMemcpy(fb_rgb, d_fb, fb_floats * sizeof(float), hipMemcpyDeviceToHost));
+        } else { // copy back only this shard's blocks; other pixels of fb_rgb stay untouched
+            for (uint64_t b = L.shard_index; b < n_blocks; b += L.shard_count) {
+                uint64_t first = b * block, last = std::min<uint64_t>(first + block, n_pix);
+                HIP_TRY(hipMemcpy(fb_rgb + 3 * first, d_fb + 3 * first, (last - first) * 3 * sizeof(float), hipMemcpyDeviceToHost));
+            }
+        }
+    }
+    if (stats) {
+        DevStats h{};
+        HIP_TRY(hipMemcpy(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+        stats->samples = h.samples;
+        stats->casts = h.casts;
+        stats->nodes_visited = h.nodes;
+        stats->box_tests = h.box_tests;
+        stats->tri_tests = h.tri_tests;
+        stats->shaded_hits = h.shaded;
+        stats->light_queries = h.lq;
+        stats->light_nodes = h.lnodes;
+        stats->light_box_tests = h.lbox;
+        stats->light_tri_tests = h.ltri;
+        stats->light_hits = h.lhits;
+        stats->texel_fetches = h.texels;
+        stats->kernel_ms = ms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_cast_rays(rt_scene *s, const float *rays, uint32_t n, uint32_t *prim_out, float *bct_out) {
+    if (!s || (n && (!rays || !prim_out || !bct_out)))
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_cast_rays: null argument");
+    if (n == 0)
+        return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    float *d_rays = nullptr, *d_bct = nullptr;
+    uint32_t *d_prim = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_rays, (size_t)n * 24));
+    HIP_TRY(hipMalloc((void **)&d_bct, (size_t)n * 12));
+    HIP_TRY(hipMalloc((void **)&d_prim, (size_t)n * 4));
+    int rc = RT_OK;
+    hipError_t e = hipMemcpy(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = rt::launch_cast(s->dev, d_rays, n, d_prim, d_bct, s->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy(prim_out, d_prim, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(bct_out, d_bct, (size_t)n * 12, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        rc = rt::fail(RT_ERR_HIP, std::string("rt_cast_rays: ") + hipGetErrorString(e));
+    (void)hipFree(d_rays);
+    (void)hipFree(d_bct);
+    (void)hipFree(d_prim);
+    return rc;
+}
+
+extern "C" int rt_light_pdf(rt_scene *s, const float *rays, uint32_t n, float *pdf_out) {
+    if (!s || (n && (!rays || !pdf_out)))
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_light_pdf: null argument");
+    if (n == 0)
+        return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    float *d_rays = nullptr, *d_pdf = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_rays, (size_t)n * 24));
+    HIP_TRY(hipMalloc((void **)&d_pdf, (size_t)n * 4));
+    int rc = RT_OK;
+    hipError_t e = hipMemcpy(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = rt::launch_light_pdf(s->dev, d_rays, n, d_pdf, s->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy(pdf_out, d_pdf, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        rc = rt::fail(RT_ERR_HIP, std::string("rt_light_pdf: ") + hipGetErrorString(e));
+    (void)hipFree(d_rays);
+    (void)hipFree(d_pdf);
+    return rc;
+}
+
+extern "C" int rt_bvh_info(rt_scene *s, int which, uint32_t *n_nodes, uint32_t *n_objects, uint32_t *root, uint32_t *nodes_out,
+                           uint32_t *order_out) {
+    if (!s || which < 0 || which > 1)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_bvh_info: bad argument");
+    const rt::HostBvh &b = s->host_bvh[which];
+    if (n_nodes)
+        *n_nodes = (uint32_t)b.nodes.size();
+    if (n_objects)
+        *n_objects = (uint32_t)b.order.size();
+    if (root)
+        *root = b.root;
+    if (nodes_out) {
+        for (size_t i = 0; i < b.nodes.size(); ++i) {
+            const rt::HostNode &nd = b.nodes[i];
+            std::memcpy(nodes_out + 10 * i, nd.lo, 12);
+            std::memcpy(nodes_out + 10 * i + 3, nd.hi, 12);
+            nodes_out[10 * i + 6] = nd.left;
+            nodes_out[10 * i + 7] = nd.right;
+            nodes_out[10 * i + 8] = nd.obj_begin;
+            nodes_out[10 * i + 9] = nd.obj_end;
+        }
+    }
+    if (order_out && !b.order.empty())
+        std::memcpy(order_out, b.order.data(), b.order.size() * sizeof(uint32_t));
+    return RT_OK;
+}

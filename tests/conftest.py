@@ -1,0 +1,93 @@
+"""pytest configuration: markers, import paths, shared scene fixtures.
+
+`-m "not gpu"` tests: the oracle against golden vectors, host logic (loader, film, BVH builder through the oracle),
+ABI symbol checks. `-m gpu` tests: parity of the HIP path (through the C-ABI) against the oracle on the same
+seeded inputs. /root/reference is never read at test time; tests that need the compiled reference
+(oracle/_ref/*) skip where it is absent.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "oracle") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def rt():
+    return importlib.import_module("raytracing-course-hw-public_amd")
+
+
+@pytest.fixture(scope="session")
+def sg(rt):
+    return rt.scenegen
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as o
+
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def gpu(rt):
+    """Fails (not skips) when the HIP library or the GPU is missing: there is no CPU fallback to hide behind."""
+    rt.lib()
+    n = rt.device_count()
+    assert n >= 1, "no HIP device visible: -m gpu tests need an MI355X"
+    return rt
+
+
+def golden_scene_specs():
+    """The small scenes used for golden vectors and GPU parity (name -> generator kwargs)."""
+    return {
+        # untextured diffuse + emissive, closed room, alpha pass-through materials
+        "room_plain": dict(kind="room", n_random=600, seed=11, n_lights=4, n_materials=8, tex_size=0, alpha_fraction=0.25),
+        # textured (colour + normal + MR), smooth normals
+        "room_textured": dict(kind="room", n_random=500, seed=12, n_lights=3, n_materials=6, tex_size=16, n_tex_sets=2, alpha_fraction=0.15, smooth_normals=True),
+        # no lights at all: cosine-only sampling against the white environment, open scene
+        "open_nolight": dict(kind="room", n_random=400, seed=13, n_lights=0, n_materials=6, tex_size=0, open_room=True),
+        # S-small: boxes + emissive triangles (axis-aligned, flat AABBs: the hard case for bit-exact traversal)
+        "boxes": dict(kind="boxes", n_boxes=24, seed=14, n_lights=3),
+    }
+
+
+def make_scene(sg, spec):
+    spec = dict(spec)
+    kind = spec.pop("kind")
+    if kind == "room":
+        return sg.room_scene(**spec)
+    if kind == "boxes":
+        return sg.boxes_scene(**spec)
+    raise ValueError(kind)
+
+
+@pytest.fixture(scope="session")
+def scenes(sg):
+    return {name: make_scene(sg, spec) for name, spec in golden_scene_specs().items()}
+
+
+def random_rays(scene, n, seed):
+    """Rays with origins inside the scene bounds and random directions, plus some axis-parallel ones."""
+    rng = np.random.default_rng(seed)
+    lo = scene.positions.reshape(-1, 3).min(axis=0)
+    hi = scene.positions.reshape(-1, 3).max(axis=0)
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    k = max(1, n // 16)
+    axes = np.eye(3, dtype=np.float32)[rng.integers(0, 3, size=k)] * rng.choice([-1.0, 1.0], size=(k, 1)).astype(np.float32)
+    d[:k] = axes
+    return np.concatenate([o, d.astype(np.float32)], axis=1).astype(np.float32)
