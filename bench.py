@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the render-loop hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): Msamples/s, whole job, on the Sponza-sized synthetic scene at 1000x1000 ("S-sponza",
+SURVEY.md 8d: 262 144 random triangles in a closed 40x16x20 room + 12 wall triangles + 16 emissive ceiling triangles,
+16 procedural 1024^2 RGBA8 texture sets, 66 materials, white environment, ray_depth 8) — the reference ships no
+Sponza asset, so this is the "Sponza-sized synthetic triangle set" BASELINE.json names.
+
+One step = one pass of the hot path over one batch = one full render of the 1000x1000 image: rt_render() through the
+C-ABI with the framebuffer resident in HBM (RT_FLAG_DEVICE_FB) + for N > 1 the RCCL gather of the float3
+framebuffer to rank 0. Scene upload and BVH build happen once before the timed region, like the reference's
+RaytracerStaticContext (raytracer.h:633) precedes its pixel loop.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the image is sharded in interleaved 8-row tiles
+(block b -> rank b % N), scene replicated per GPU; weak scaling: SPP = 64 * N so per-GPU work is fixed.
+
+Extra objects on the JSON line: "roofline" (algorithmic bytes of SURVEY 8d from the instrumented kernel's event
+counters / HIP-event kernel time, against 8 TB/s HBM) and "cpu_baseline" (the CPU oracle = port of the reference
+algorithm, timed on this box's host cores on a bounded sample of the same workload; rank 0, N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH = HEIGHT = 1000
+SPP_PER_GPU = 64
+N_TRIANGLES = 262144
+TEX_SIZE = 1024
+SHARD_ROWS = 8
+SEED = 0x5EED5EED
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes(st: dict, n_pixels: int) -> float:
+    """layout-independent event counts x the reference's record sizes. Cache hits do not reduce it."""
+    trav = st["box_tests"] * 24 + st["nodes_visited"] * 16 + st["tri_tests"] * 36
+    light = st["light_box_tests"] * 24 + st["light_nodes"] * 16 + st["light_tri_tests"] * 36
+    shade = st["shaded_hits"] * (96 + 72) + st["texel_fetches"] * 16
+    return float(trav + light + shade + 12 * n_pixels)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default 64 x gpus)")
+    ap.add_argument("--triangles", type=int, default=N_TRIANGLES)
+    ap.add_argument("--tex-size", type=int, default=TEX_SIZE)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # imported BEFORE the HIP library so that one HIP runtime serves both (same soname)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    rt = importlib.import_module("raytracing-course-hw-public_amd")
+    W, H = args.width, args.height
+    spp = args.spp if args.spp > 0 else SPP_PER_GPU * world
+    n_pix = W * H
+
+    t0 = time.time()
+    scene = rt.scenegen.room_scene(args.triangles, seed=SEED, tex_size=args.tex_size, n_tex_sets=16, n_materials=64, n_lights=16,
+                                   light_strength=20.0, alpha_fraction=0.02, offset=0.15,
+                                   camera=rt.scenegen.look_camera((-15.0, 4.0, 0.0), yaw_deg=-90.0, yfov=0.9, aspect=W / H))
+    t_gen = time.time() - t0
+    t0 = time.time()
+    dev = rt.DeviceScene(scene, device=local_rank)
+    t_create = time.time() - t0
+
+    block = SHARD_ROWS * W
+    fb = torch.zeros(n_pix * 3, dtype=torch.float32, device=device)
+    n_blocks = (n_pix + block - 1) // block
+    # gather plumbing: equal-sized padded slabs of this rank's blocks -> rank 0
+    my_blocks = list(range(rank, n_blocks, world))
+    max_blocks = (n_blocks + world - 1) // world
+    slab = torch.zeros(max_blocks * block * 3, dtype=torch.float32, device=device)
+    gathered = [torch.empty_like(slab) for _ in range(world)] if (world > 1 and rank == 0) else None
+    full = torch.zeros(n_blocks * block * 3, dtype=torch.float32, device=device) if rank == 0 else None
+
+    def step():
+        _, st = dev.run_raytracer(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr())
+        if world > 1:
+            # compact this rank's interleaved blocks into a slab, RCCL gather over xGMI, de-interleave on rank 0
+            padded = torch.zeros(n_blocks * block * 3, dtype=torch.float32, device=device)
+            padded[: n_pix * 3] = fb
+            mine = padded.view(n_blocks, block * 3)[rank::world]
+            slab[: mine.numel()] = mine.reshape(-1)
+            dist.gather(slab, gathered, dst=0)
+            if rank == 0:
+                fv = full.view(n_blocks, block * 3)
+                for r in range(world):
+                    nb = len(range(r, n_blocks, world))
+                    fv[r::world] = gathered[r][: nb * block * 3].view(nb, block * 3)
+        return st
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()
+        kernel_ms.append(st["kernel_ms"])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_samples = float(n_pix) * spp * args.steps
+    value = total_samples / elapsed / 1e6
+
+    # ---- roofline of the dominant (only) kernel: algorithmic bytes per launch / average launch duration
+    _, cst = dev.run_raytracer(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr(), counters=True)
+    my_pixels = sum(min((b + 1) * block, n_pix) - b * block for b in my_blocks)
+    bytes_per_launch = algorithmic_bytes(cst, my_pixels)
+    avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
+    achieved = bytes_per_launch / avg_kernel_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == f"S-sponza {W}x{H}x{spp} n={args.triangles}" and world == 1:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm",
+        "achieved": round(achieved, 2),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": traffic,
+        "kernel": "render_kernel<RT_RNG_DEVICE>",
+        "kernel_ms": round(avg_kernel_s * 1e3, 3),
+        "algorithmic_bytes_per_sample": round(bytes_per_launch / (my_pixels * spp), 1),
+    }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle
+
+        orc = oracle.OracleScene(scene)
+        cores = os.cpu_count() or 1
+        # bounded sample of the same workload: every 16th 256-pixel span of the same image, reference RNG + libm
+        # (the reference CPU path, raytracer.h:636-662), SPP chosen from a short probe to land near --cpu-seconds.
+        share = 16
+        _, p = orc.run_raytracer(W, H, 1, rng_mode=rt.RT_RNG_REFERENCE, shard_index=0, shard_count=share, shard_block=256, threads=cores)
+        rate = p["samples"] / (p["total_ms"] / 1e3)
+        cpu_spp = int(max(1, min(64, round(args.cpu_seconds * rate / p["samples"]))))
+        _, c = orc.run_raytracer(W, H, cpu_spp, rng_mode=rt.RT_RNG_REFERENCE, shard_index=0, shard_count=share, shard_block=256, threads=cores)
+        cpu_baseline = {
+            "value": round(c["samples"] / (c["total_ms"] / 1e3) / 1e6, 4),
+            "unit": "Msamples/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"same scene, every {share}th 256-pixel span of the {W}x{H} image at {cpu_spp} SPP = {c['samples']} samples, {c['total_ms'] / 1e3:.1f} s, reference RNG + libm",
+        }
+        orc.close()
+
+    if rank == 0:
+        out = {
+            "metric": "Msamples/sec (whole node) on Sponza 1000x1000",
+            "value": round(value, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"S-sponza synthetic (Sponza-sized): {args.triangles}+28 triangles, 16x3 {args.tex_size}^2 RGBA8 textures, {W}x{H}, {spp} SPP, ray_depth 8, device RNG",
+                "width": W,
+                "height": H,
+                "spp": spp,
+                "triangles": int(scene.n_triangles),
+                "sharding": f"interleaved {SHARD_ROWS}-row tiles over {world} GPU(s), RCCL gather of float3 framebuffer" if world > 1 else "single GPU",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "setup_s": {"scene_generation": round(t_gen, 2), "rt_create_bvh_upload": round(t_create, 2)},
+        }
+        print(json.dumps(out), flush=True)
+    dev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

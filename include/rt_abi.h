@@ -128,7 +128,9 @@ typedef struct rt_params {
 
 enum {
     RT_FLAG_NONE = 0,
-    RT_FLAG_DEVICE_FB = 1 /* fb_rgb is a device pointer (HBM resident); no D2H copy */
+    RT_FLAG_DEVICE_FB = 1, /* fb_rgb is a device pointer (HBM resident); no D2H copy */
+    RT_FLAG_COUNTERS = 2   /* run the instrumented kernel variant and fill the event counters of rt_stats
+                              (slower; timing fields are filled whenever `stats` is non-NULL) */
 };
 
 /* Per-render statistics (optional out-parameter). Counters are layout independent event counts in the

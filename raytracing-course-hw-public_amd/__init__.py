@@ -21,6 +21,7 @@ from ._ctypes_abi import (
     ABI_PROTOTYPES,
     ERROR_NAMES,
     HOST_PROTOTYPES,
+    RT_FLAG_COUNTERS,
     RT_FLAG_DEVICE_FB,
     RT_OK,
     RT_RNG_DEVICE,
@@ -138,13 +139,15 @@ class DeviceScene:
         shard_block: int = 0,
         out: Optional[np.ndarray] = None,
         device_fb: int = 0,
+        counters: bool = False,
     ):
         """run_raytracer(scene, image) (raytracer.h:629): returns (linear float framebuffer (H,W,3), stats dict).
-        With `device_fb` (a device pointer) the framebuffer stays in HBM and None is returned for it."""
-        p = RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block, 0)
+        With `device_fb` (a device pointer) the framebuffer stays in HBM and None is returned for it.
+        `counters=True` runs the instrumented kernel variant and fills the event counters of the stats."""
+        p = RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block, RT_FLAG_COUNTERS if counters else 0)
         st = RtStats()
         if device_fb:
-            p.flags = RT_FLAG_DEVICE_FB
+            p.flags |= RT_FLAG_DEVICE_FB
             _check(lib().rt_render(self._h, C.byref(p), C.c_void_p(device_fb), C.byref(st)))
             return None, st.as_dict()
         fb = out if out is not None else np.zeros((height, width, 3), dtype=np.float32)

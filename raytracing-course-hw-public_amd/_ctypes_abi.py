@@ -14,6 +14,7 @@ RT_TEX_NONE = -1
 RT_RNG_DEVICE = 0
 RT_RNG_REFERENCE = 1
 RT_FLAG_DEVICE_FB = 1
+RT_FLAG_COUNTERS = 2
 
 RT_OK = 0
 ERROR_NAMES = {

@@ -286,10 +286,11 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
     L.items_per_block = block / unit;
     // work items of this shard: blocks b = shard_index, shard_index + count, ... below ceil(n_pix / block)
     const uint64_t n_blocks = ((uint64_t)n_pix + block - 1) / block;
-    uint64_t items = 0;
+    uint64_t items = 0, local_pixels = 0;
     for (uint64_t b = L.shard_index; b < n_blocks; b += L.shard_count) {
         uint64_t first = b * block, last = std::min<uint64_t>(first + block, n_pix);
         items += (last - first + unit - 1) / unit;
+        local_pixels += last - first;
     }
     L.n_items = (uint32_t)items;
     // gen_ray's tan terms (raytracer.h:531-535) and Camera::fov_y (scene.h:69-71), float overloads
@@ -315,9 +316,10 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
     }
     L.fb = d_fb;
     L.counter = s->d_counter;
-    L.stats = stats ? s->d_stats : nullptr;
+    const bool counters = stats && (p->flags & RT_FLAG_COUNTERS);
+    L.stats = counters ? s->d_stats : nullptr;
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), s->stream));
-    if (stats)
+    if (counters)
         HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DevStats), s->stream));
 
     int blocks = (int)std::min<uint64_t>((items + 255) / 256, (uint64_t)s->num_cus * s->blocks_per_cu);
@@ -325,7 +327,7 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
         blocks = 1;
     if (L.n_items > 0) {
         HIP_TRY(hipEventRecord(s->ev0, s->stream));
-        HIP_TRY(rt::launch_render(s->dev, L, stats != nullptr, blocks, s->stream));
+        HIP_TRY(rt::launch_render(s->dev, L, counters, blocks, s->stream));
         HIP_TRY(hipEventRecord(s->ev1, s->stream));
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -345,8 +347,9 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
     }
     if (stats) {
         DevStats h{};
-        HIP_TRY(hipMemcpy(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
-        stats->samples = h.samples;
+        if (counters)
+            HIP_TRY(hipMemcpy(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+        stats->samples = counters ? h.samples : local_pixels * p->samples;
         stats->casts = h.casts;
         stats->nodes_visited = h.nodes;
         stats->box_tests = h.box_tests;

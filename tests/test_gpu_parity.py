@@ -92,7 +92,7 @@ def test_render_device_rng_matches_oracle(pairs, gpu, name):
     (observed: bit-identical), identical event counters."""
     dev, orc, _ = pairs[name]
     W, H, SPP = 48, 40, 6
-    gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=1234)
+    gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=1234, counters=True)
     ofb, ost = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=1234)
     assert np.isfinite(gfb).all()
     err = _rel_err(gfb, ofb)
