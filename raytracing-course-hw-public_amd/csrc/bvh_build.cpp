@@ -189,8 +189,10 @@ FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions) {
         const HostNode &nd = bvh.nodes[i];
         if (nd.left != RT_NONE || nd.right != RT_NONE)
             dev_index[i] = n_inner++;
-        else if (nd.obj_end > nd.obj_begin)
-            f.tris[nd.obj_end - 1].flags |= 1u;
+        else if (nd.obj_end > nd.obj_begin) {
+            f.tris[nd.obj_end - 1].flags |= 1u; // last triangle of its leaf
+            f.tris[nd.obj_begin].flags |= 2u;   // first triangle of its leaf
+        }
     }
     auto ref_of = [&](uint32_t node) -> uint32_t {
         const HostNode &nd = bvh.nodes[node];

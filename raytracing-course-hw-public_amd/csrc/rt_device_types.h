@@ -32,7 +32,7 @@ struct alignas(16) DevTri {
     float v[3]; // b - a   (triangle::v geometry.h:473)
     float u[3]; // c - a   (triangle::u geometry.h:475)
     uint32_t prim;  // original triangle index (scene.objects position)
-    uint32_t flags; // bit0: last triangle of its leaf
+    uint32_t flags; // bit0: last triangle of its leaf, bit1: first triangle of its leaf
     uint32_t pad;
 };
 static_assert(sizeof(DevTri) == 48, "DevTri must be 48 bytes");

@@ -142,11 +142,25 @@ template <> struct Rng<RT_RNG_REFERENCE> {
 template <class R> DEV float uniform_real(R &r, float a, float b) { return r.canonical() * (b - a) + a; }
 
 // ---------------------------------------------------------------------------------------------- primitives
-// intersect(ray, aabb, min_dst) bvh.h:137-152. Division is IEEE; min/max keep std::min/max operand order; the
-// component reductions follow std::max_element / std::min_element (first extremum, geometry.h:42-50).
-DEV bool box_hit(const float *bmin, const float *bmax, V3 o, V3 d, float min_dst, float &dist) {
-    V3 i1 = (ld3(bmin) - o) / d;
-    V3 i2 = (ld3(bmax) - o) / d;
+// Exact quotient a/d from a precomputed r = RN(1/d): two FMA correction steps (Markstein: with r the correctly
+// rounded reciprocal and a faithful q, q + (a - d*q)*r rounds to RN(a/d); the first step makes q faithful). Valid
+// only while a, d, q and the residuals stay in the normal range — the caller checks |d| and |q| in [2^-40, 2^40] and
+// otherwise falls back to the IEEE division. 5 VALU ops instead of the ~11-op division expansion with v_rcp.
+DEV float div_exact_fast(float a, float d, float r) {
+    float q0 = a * r;
+    float e0 = __builtin_fmaf(-d, q0, a);
+    float q1 = __builtin_fmaf(e0, r, q0);
+    float e1 = __builtin_fmaf(-d, q1, a);
+    return __builtin_fmaf(e1, r, q1);
+}
+constexpr float RANGE_LO = 9.094947017729282e-13f; // 2^-40
+constexpr float RANGE_HI = 1099511627776.0f;       // 2^40
+
+// intersect(ray, aabb, min_dst) bvh.h:137-152, reference form: IEEE division, std::min/max operand order kept by
+// explicit selects, component reductions as std::max_element / std::min_element (first extremum, geometry.h:42-50).
+DEV bool box_hit_exact(V3 bmin, V3 bmax, V3 o, V3 d, float min_dst, float &dist) {
+    V3 i1 = (bmin - o) / d;
+    V3 i2 = (bmax - o) / d;
     V3 mn = {rmin(i1.x, i2.x), rmin(i1.y, i2.y), rmin(i1.z, i2.z)};
     V3 mx = {rmax(i1.x, i2.x), rmax(i1.y, i2.y), rmax(i1.z, i2.z)};
     float t_min = mn.x;
@@ -166,15 +180,46 @@ DEV bool box_hit(const float *bmin, const float *bmax, V3 o, V3 d, float min_dst
     return false;
 }
 
+// Same slab test on the fast path: the six quotients come from div_exact_fast; when all of them are finite, non-zero
+// and inside [2^-40, 2^40] (so: no NaN, no +-0, no inf) v_min/v_max agree with the select forms bit for bit. `ok`
+// reports whether that held; if not the caller redoes the box with box_hit_exact.
+DEV bool box_hit_fast(V3 bmin, V3 bmax, V3 o, V3 d, V3 r, float min_dst, float &dist, bool &ok) {
+    V3 a1 = bmin - o, a2 = bmax - o;
+    float q1x = div_exact_fast(a1.x, d.x, r.x), q1y = div_exact_fast(a1.y, d.y, r.y), q1z = div_exact_fast(a1.z, d.z, r.z);
+    float q2x = div_exact_fast(a2.x, d.x, r.x), q2y = div_exact_fast(a2.y, d.y, r.y), q2z = div_exact_fast(a2.z, d.z, r.z);
+    float lo = fminf(fminf(fminf(__builtin_fabsf(q1x), __builtin_fabsf(q1y)), fminf(__builtin_fabsf(q1z), __builtin_fabsf(q2x))),
+                     fminf(__builtin_fabsf(q2y), __builtin_fabsf(q2z)));
+    float hi = fmaxf(fmaxf(fmaxf(__builtin_fabsf(q1x), __builtin_fabsf(q1y)), fmaxf(__builtin_fabsf(q1z), __builtin_fabsf(q2x))),
+                     fmaxf(__builtin_fabsf(q2y), __builtin_fabsf(q2z)));
+    // NaNs: fminf/fmaxf drop them, so test every |q| <= hi chain is not enough; a NaN quotient needs a NaN/inf/0
+    // input, which also shows up as lo == 0 or hi == inf except for NaN inputs themselves -> check q == q below.
+    bool no_nan = (q1x == q1x) & (q1y == q1y) & (q1z == q1z) & (q2x == q2x) & (q2y == q2y) & (q2z == q2z);
+    ok = no_nan & (lo >= RANGE_LO) & (hi <= RANGE_HI);
+    float t_min = fmaxf(fmaxf(fminf(q1x, q2x), fminf(q1y, q2y)), fminf(q1z, q2z));
+    float t_max = fminf(fminf(fmaxf(q1x, q2x), fmaxf(q1y, q2y)), fmaxf(q1z, q2z));
+    dist = fmaxf(t_min, min_dst);
+    return (t_min <= t_max) & (t_max >= min_dst);
+}
+
 // intersect_ray_triangle + intersect(ray, triangle, min_dst) bvh.h:36-65 (Cramer; xs = (b, c, t)).
 // det(c1,c2,c3) = dot(c1, crs(c2,c3)) (geometry.h:26-29); crs(u, -d) is shared by two determinants.
-DEV bool tri_hit(const DevTri &tr, V3 o, V3 d, float min_dst, V3 &xs_out) {
-    V3 av = ld3(tr.v), au = ld3(tr.u);
+// Division-free early reject: a numerator whose sign certainly differs from the denominator's (|n| > 2^-60,
+// |den| < 2^60, so the quotient cannot round to -0) makes xs.x >= 0, xs.y >= 0 or xs.z >= min_dst false without
+// computing the quotient. Everything else takes the reference's three IEEE divisions.
+DEV bool surely_negative(float n, float den) {
+    const uint32_t sn = __float_as_uint(n) ^ __float_as_uint(den);
+    return (sn >> 31) & (__builtin_fabsf(n) > 8.673617379884035e-19f) & (__builtin_fabsf(n) < RT_INF);
+}
+DEV bool tri_hit(V3 ta, V3 av, V3 au, V3 o, V3 d, float min_dst, V3 &xs_out) {
     V3 at = -d;
-    V3 y = o - ld3(tr.a);
+    V3 y = o - ta;
     V3 c_ut = crs(au, at);
     float den = dot(av, c_ut);
-    V3 xs = V3{dot(y, c_ut), dot(av, crs(y, at)), dot(av, crs(au, y))} / den;
+    float nx = dot(y, c_ut), ny = dot(av, crs(y, at)), nz = dot(av, crs(au, y));
+    const bool den_ok = (__builtin_fabsf(den) < 1.152921504606847e18f) & (den != 0.0f); // finite, |den| < 2^60
+    if (den_ok & (surely_negative(nx, den) | surely_negative(ny, den) | surely_negative(nz, den)))
+        return false;
+    V3 xs = V3{nx, ny, nz} / den;
     if (xs.x >= 0 && xs.y >= 0 && xs.x + xs.y <= 1 && xs.z >= min_dst) {
         xs_out = xs;
         return true;
@@ -182,16 +227,6 @@ DEV bool tri_hit(const DevTri &tr, V3 o, V3 d, float min_dst, V3 &xs_out) {
     return false;
 }
 
-DEV DevNode load_node(const DevNode *nodes, uint32_t idx) {
-    DevNode n;
-    const float4 *p = reinterpret_cast<const float4 *>(nodes + idx);
-    float4 *q = reinterpret_cast<float4 *>(&n);
-    q[0] = p[0];
-    q[1] = p[1];
-    q[2] = p[2];
-    q[3] = p[3];
-    return n;
-}
 DEV DevTri load_tri(const DevTri *tris, uint32_t idx) {
     DevTri t;
     const float4 *p = reinterpret_cast<const float4 *>(tris + idx);
@@ -207,144 +242,211 @@ struct Hit {
     float b, c, t;
 };
 
-// BVH::intersect_ray (bvh.h:170-180, 195-235) with an explicit stack.
-//   frame = {far child ref, far entry distance d_far, local best of the ENCLOSING subtree at push time}
-//   t_loc = local best t of the subtree being traversed (NaN = no hit yet; fminf ignores NaN operands).
-// On pop the far sibling is visited iff the near subtree found nothing or found t > d_far (bvh.h:221), then the
-// near result is merged into the enclosing subtree's local best. The global best uses the reference's strict
-// "replace iff existing t > new t" rule (bvh.h:132) in DFS order, which equals the nested update_intersection calls.
-template <bool STATS>
-DEV Hit closest_hit(const DevBvh &bvh, V3 o, V3 d, float min_dst, uint32_t *stk_ref, float *stk_d, float *stk_loc, LaneStats<STATS> &st) {
-    Hit best{RT_NONE, 0.f, 0.f, 0.f};
-    if (bvh.root == RT_NONE || bvh.n_tris == 0)
-        return best;
-    constexpr uint32_t DONE = 0xFFFFFFFEu, POP = 0xFFFFFFFDu;
-    uint32_t cur = bvh.root;
-    int sp = 0;
-    float t_loc = RT_NAN;
-    while (cur != DONE) {
-        if (!(cur & RT_LEAF_FLAG)) {
-            st.node();
-            st.box(2);
-            const DevNode n = load_node(bvh.nodes, cur);
-            float dl, dr;
-            bool hl = box_hit(n.lmin, n.lmax, o, d, min_dst, dl);
-            bool hr = box_hit(n.rmin, n.rmax, o, d, min_dst, dr);
-            if (hl && hr) {
-                uint32_t near = n.left, far = n.right;
-                float dfar = dr;
-                if (dl > dr) { // bvh.h:216 (ties keep left first)
-                    near = n.right;
-                    far = n.left;
-                    dfar = dl;
-                }
-                stk_ref[sp] = far;
-                stk_d[sp] = dfar;
-                stk_loc[sp] = t_loc;
-                ++sp;
-                t_loc = RT_NAN;
-                cur = near;
-            } else if (hl) {
-                cur = n.left;
-            } else if (hr) {
-                cur = n.right;
-            } else {
-                cur = POP;
-            }
+// ---------------------------------------------------------------------------------------------- traversal stack
+// Deferred far siblings: {child ref, far entry distance, enclosing subtree's local best}. The first LDS_DEPTH
+// positions live in LDS, one column per thread (bank = thread % 32: conflict free whatever the lanes' depths);
+// deeper positions fall back to per-lane scratch. sp counts only ancestors whose BOTH children were hit, so the LDS
+// part serves almost every access (DESIGN.md "traversal stack").
+constexpr int LDS_DEPTH = 12;
+struct StackMem {
+    uint32_t *lds; // [3][LDS_DEPTH][256] dwords, this thread's column starts at lds + threadIdx.x
+    uint32_t ov_ref[RT_MAX_STACK - LDS_DEPTH];
+    float ov_d[RT_MAX_STACK - LDS_DEPTH];
+    float ov_loc[RT_MAX_STACK - LDS_DEPTH];
+    DEV void push(int sp, uint32_t ref, float d, float loc) {
+        if (sp < LDS_DEPTH) {
+            lds[(0 * LDS_DEPTH + sp) * 256] = ref;
+            lds[(1 * LDS_DEPTH + sp) * 256] = __float_as_uint(d);
+            lds[(2 * LDS_DEPTH + sp) * 256] = __float_as_uint(loc);
         } else {
-            st.node();
-            uint32_t k = cur & ~RT_LEAF_FLAG;
-            uint32_t last;
-            do {
-                const DevTri tr = load_tri(bvh.tris, k);
-                st.tri();
-                V3 xs;
-                if (tri_hit(tr, o, d, min_dst, xs)) {
-                    if (best.k == RT_NONE || best.t > xs.z) {
-                        best.k = k;
-                        best.b = xs.x;
-                        best.c = xs.y;
-                        best.t = xs.z;
-                    }
-                    t_loc = fminf(t_loc, xs.z);
-                }
-                last = tr.flags & 1u;
-                ++k;
-            } while (!last);
-            cur = POP;
-        }
-        while (cur == POP) {
-            if (sp == 0) {
-                cur = DONE;
-                break;
-            }
-            --sp;
-            const float t_near = t_loc;
-            const float dfar = stk_d[sp];
-            t_loc = fminf(stk_loc[sp], t_near);
-            if (!(t_near <= dfar)) // !has || t_near > d_far (bvh.h:221)
-                cur = stk_ref[sp];
+            ov_ref[sp - LDS_DEPTH] = ref;
+            ov_d[sp - LDS_DEPTH] = d;
+            ov_loc[sp - LDS_DEPTH] = loc;
         }
     }
-    return best;
+    DEV void pop(int sp, uint32_t &ref, float &d, float &loc) {
+        if (sp < LDS_DEPTH) {
+            ref = lds[(0 * LDS_DEPTH + sp) * 256];
+            d = __uint_as_float(lds[(1 * LDS_DEPTH + sp) * 256]);
+            loc = __uint_as_float(lds[(2 * LDS_DEPTH + sp) * 256]);
+        } else {
+            ref = ov_ref[sp - LDS_DEPTH];
+            d = ov_d[sp - LDS_DEPTH];
+            loc = ov_loc[sp - LDS_DEPTH];
+        }
+    }
+    // light-pdf traversal only needs child refs (bvh.h:237-260 has no ordering / pruning)
+    DEV void push_ref(int sp, uint32_t ref) {
+        if (sp < LDS_DEPTH)
+            lds[(0 * LDS_DEPTH + sp) * 256] = ref;
+        else
+            ov_ref[sp - LDS_DEPTH] = ref;
+    }
+    DEV uint32_t pop_ref(int sp) { return sp < LDS_DEPTH ? lds[(0 * LDS_DEPTH + sp) * 256] : ov_ref[sp - LDS_DEPTH]; }
+};
+#define STACK_LDS_DWORDS (3 * LDS_DEPTH * 256)
+
+// ---------------------------------------------------------------------------------------------- closest hit
+// BVH::intersect_ray (bvh.h:170-180, 195-235) as a resumable per-lane state machine: one call of trav_step visits
+// ONE record — an inner node (both child boxes, 64 B) or one leaf triangle (48 B) — so every lane of the wavefront
+// issues exactly one gather per step whatever it is doing, and a lane can be parked between steps while others shade.
+//   frame = {far child ref, far entry distance d_far, local best of the ENCLOSING subtree at push time}
+//   t_loc = local best t of the subtree being traversed (NaN = no hit yet; fminf ignores NaN operands).
+// On pop the far sibling is visited iff the near subtree found nothing or found t > d_far (bvh.h:221): the
+// reference prunes against the near subtree's local best only. The global best uses the strict "replace iff existing
+// t > new t" rule (bvh.h:132) in DFS order, which equals the nested update_intersection calls.
+constexpr uint32_t T_DONE = 0xFFFFFFFEu, T_POP = 0xFFFFFFFDu;
+struct Trav {
+    V3 o, d, r; // r = 1/d (IEEE) for div_exact_fast
+    uint32_t cur;
+    int sp;
+    float t_loc;
+    Hit best;
+    bool fast; // every |d_i| in [2^-40, 2^40]
+};
+DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
+    T.o = o;
+    T.d = d;
+    T.r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float lo = fminf(fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    float hi = fmaxf(fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    T.fast = (d.x == d.x) & (d.y == d.y) & (d.z == d.z) & (lo >= RANGE_LO) & (hi <= RANGE_HI);
+    T.cur = (bvh.root == RT_NONE || bvh.n_tris == 0) ? T_DONE : bvh.root;
+    T.sp = 0;
+    T.t_loc = RT_NAN;
+    T.best = Hit{RT_NONE, 0.f, 0.f, 0.f};
+}
+
+template <bool STATS> DEV void trav_step(Trav &T, const DevBvh &bvh, StackMem &stk, float min_dst, LaneStats<STATS> &st) {
+    const bool leaf = (T.cur & RT_LEAF_FLAG) != 0;
+    const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (T.cur & ~RT_LEAF_FLAG)) : reinterpret_cast<const float4 *>(bvh.nodes + T.cur);
+    const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+    if (!leaf) {
+        const float4 r3 = p[3];
+        st.node();
+        st.box(2);
+        // DevNode: lmin.xyz lmax.xyz rmin.xyz rmax.xyz left right
+        const V3 lmin = mk(r0.x, r0.y, r0.z), lmax = mk(r0.w, r1.x, r1.y), rmn = mk(r1.z, r1.w, r2.x), rmx = mk(r2.y, r2.z, r2.w);
+        const uint32_t left = __float_as_uint(r3.x), right = __float_as_uint(r3.y);
+        float dl, dr;
+        bool hl, hr;
+        bool okl = false, okr = false;
+        if (T.fast) {
+            hl = box_hit_fast(lmin, lmax, T.o, T.d, T.r, min_dst, dl, okl);
+            hr = box_hit_fast(rmn, rmx, T.o, T.d, T.r, min_dst, dr, okr);
+        }
+        if (!(okl & okr)) { // rare: a quotient was 0 / inf / NaN / out of range -> reference arithmetic
+            hl = box_hit_exact(lmin, lmax, T.o, T.d, min_dst, dl);
+            hr = box_hit_exact(rmn, rmx, T.o, T.d, min_dst, dr);
+        }
+        if (hl & hr) {
+            uint32_t near = left, far = right;
+            float dfar = dr;
+            if (dl > dr) { // bvh.h:216 (ties keep left first)
+                near = right;
+                far = left;
+                dfar = dl;
+            }
+            stk.push(T.sp, far, dfar, T.t_loc);
+            ++T.sp;
+            T.t_loc = RT_NAN;
+            T.cur = near;
+        } else if (hl) {
+            T.cur = left;
+        } else if (hr) {
+            T.cur = right;
+        } else {
+            T.cur = T_POP;
+        }
+    } else {
+        // DevTri: a.xyz v.xyz u.xyz prim flags pad
+        const uint32_t flags = __float_as_uint(r2.z);
+        if (flags & 2u)
+            st.node(); // first triangle of its leaf: one BVH::intersect_ray invocation on the leaf node
+        st.tri();
+        V3 xs;
+        if (tri_hit(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), T.o, T.d, min_dst, xs)) {
+            if (T.best.k == RT_NONE || T.best.t > xs.z) {
+                T.best.k = T.cur & ~RT_LEAF_FLAG;
+                T.best.b = xs.x;
+                T.best.c = xs.y;
+                T.best.t = xs.z;
+            }
+            T.t_loc = fminf(T.t_loc, xs.z);
+        }
+        T.cur = (flags & 1u) ? T_POP : T.cur + 1;
+    }
+    while (T.cur == T_POP) {
+        if (T.sp == 0) {
+            T.cur = T_DONE;
+            break;
+        }
+        --T.sp;
+        uint32_t ref;
+        float dfar, saved;
+        stk.pop(T.sp, ref, dfar, saved);
+        const float t_near = T.t_loc;
+        T.t_loc = fminf(saved, t_near);
+        if (!(t_near <= dfar)) // !has || t_near > d_far (bvh.h:221)
+            T.cur = ref;
+    }
 }
 
 // bvh_mix_dist::pdf (raytracer.h:363-375) = BVH::foreach_intersection (bvh.h:237-260) over the light BVH summing
 // triangle_dist::pdf_at (raytracer.h:255-261) in DFS order (node objects, left subtree, right subtree).
-template <bool STATS>
-DEV float lights_pdf(const DevScene &S, V3 x, V3 d, uint32_t *stk_ref, LaneStats<STATS> &st) {
+template <bool STATS> DEV float lights_pdf(const DevScene &S, V3 x, V3 d, StackMem &stk, LaneStats<STATS> &st) {
     const DevBvh &bvh = S.lights;
     st.lq();
     float res = 0;
     if (bvh.root != RT_NONE && bvh.n_tris != 0) {
-        constexpr uint32_t DONE = 0xFFFFFFFEu, POP = 0xFFFFFFFDu;
         uint32_t cur = bvh.root;
         int sp = 0;
-        while (cur != DONE) {
-            if (!(cur & RT_LEAF_FLAG)) {
+        while (cur != T_DONE) {
+            const bool leaf = (cur & RT_LEAF_FLAG) != 0;
+            const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (cur & ~RT_LEAF_FLAG)) : reinterpret_cast<const float4 *>(bvh.nodes + cur);
+            const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+            if (!leaf) {
+                const float4 r3 = p[3];
                 st.lnode();
                 st.lbox(2);
-                const DevNode n = load_node(bvh.nodes, cur);
+                const uint32_t left = __float_as_uint(r3.x), right = __float_as_uint(r3.y);
                 float dl, dr;
-                bool hl = box_hit(n.lmin, n.lmax, x, d, EPS, dl);
-                bool hr = box_hit(n.rmin, n.rmax, x, d, EPS, dr);
-                if (hl && hr) {
-                    stk_ref[sp++] = n.right;
-                    cur = n.left;
+                bool hl = box_hit_exact(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), x, d, EPS, dl);
+                bool hr = box_hit_exact(mk(r1.z, r1.w, r2.x), mk(r2.y, r2.z, r2.w), x, d, EPS, dr);
+                if (hl & hr) {
+                    stk.push_ref(sp++, right);
+                    cur = left;
                 } else if (hl) {
-                    cur = n.left;
+                    cur = left;
                 } else if (hr) {
-                    cur = n.right;
+                    cur = right;
                 } else {
-                    cur = POP;
+                    cur = T_POP;
                 }
             } else {
-                st.lnode();
-                uint32_t k = cur & ~RT_LEAF_FLAG;
-                uint32_t last;
-                do {
-                    const DevTri tr = load_tri(bvh.tris, k);
-                    st.ltri();
-                    V3 xs;
-                    if (tri_hit(tr, x, d, EPS, xs)) {
-                        st.lhit();
-                        const float4 aux = *reinterpret_cast<const float4 *>(S.light_aux + k);
-                        V3 y = x + d * xs.z;           // ray.at(t)
-                        V3 dir = norm(y - x);          // raytracer.h:259
-                        float mult = len2(x - y) / __builtin_fabsf(dot(dir, mk(aux.x, aux.y, aux.z))); // :79-84
-                        res += mult / aux.w;
-                    }
-                    last = tr.flags & 1u;
-                    ++k;
-                } while (!last);
-                cur = POP;
+                const uint32_t k = cur & ~RT_LEAF_FLAG;
+                const uint32_t flags = __float_as_uint(r2.z);
+                if (flags & 2u)
+                    st.lnode();
+                st.ltri();
+                V3 xs;
+                if (tri_hit(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), x, d, EPS, xs)) {
+                    st.lhit();
+                    const float4 aux = *reinterpret_cast<const float4 *>(S.light_aux + k);
+                    V3 y = x + d * xs.z;  // ray.at(t)
+                    V3 dir = norm(y - x); // raytracer.h:259
+                    float mult = len2(x - y) / __builtin_fabsf(dot(dir, mk(aux.x, aux.y, aux.z))); // :79-84
+                    res += mult / aux.w;
+                }
+                cur = (flags & 1u) ? T_POP : cur + 1;
             }
-            if (cur == POP)
-                cur = sp ? stk_ref[--sp] : DONE;
+            if (cur == T_POP)
+                cur = sp ? stk.pop_ref(--sp) : T_DONE;
         }
     }
     return res / (float)bvh.n_tris; // res / bvh->objects.size()
 }
+
 
 // ---------------------------------------------------------------------------------------------- textures
 // wrap_repeat geometry.h:517-519: std::fmod(std::fmod(x, 1) + 1, 1) evaluated in DOUBLE (float, int -> double
@@ -566,32 +668,48 @@ DEV Item map_item(const RenderLaunch &L, uint32_t item) {
     return it;
 }
 
+// Lane states of the persistent loop.
+//   ST_IDLE  : no work item (needs a refill or the image is exhausted)
+//   ST_NEW   : owns a pixel, next sample not started
+//   ST_TRAV  : a closest-hit traversal is in flight (resumable, see trav_step)
+//   ST_READY : traversal finished, hit record waits to be shaded
+enum { ST_IDLE = 0, ST_NEW = 1, ST_TRAV = 2, ST_READY = 3 };
+
+// When fewer than TRAV_MIN_LANES lanes of the wave are still traversing and others wait to be shaded, the traversal
+// loop is left: the finished lanes shade, generate their next ray and re-enter together with the stragglers, which
+// resume where they stopped. Keeps the 64-wide wave dense through the heavy-tailed traversal lengths.
+constexpr int TRAV_MIN_LANES = 40;
+
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const RenderLaunch L) {
     __shared__ float s_lin[256];
     __shared__ float s_gam[256];
+    __shared__ uint32_t s_stack[STACK_LDS_DWORDS];
     s_lin[threadIdx.x] = S.lut_linear[threadIdx.x];
     s_gam[threadIdx.x] = S.lut_gamma[threadIdx.x];
     __syncthreads();
 
     LaneStats<STATS> st;
     Rng<MODE> rng;
-    uint32_t stk_ref[RT_MAX_STACK];
-    float stk_d[RT_MAX_STACK];
-    float stk_loc[RT_MAX_STACK];
+    StackMem stk;
+    stk.lds = s_stack + threadIdx.x;
     float fold_e[RT_MAX_RAY_DEPTH * 3];
     float fold_s[RT_MAX_RAY_DEPTH * 3];
 
     const V3 cam_pos = ld3(S.cam_pos), cam_right = ld3(S.cam_right), cam_up = ld3(S.cam_up), cam_fwd = ld3(S.cam_fwd);
     const bool has_lights = S.lights.n_tris != 0; // raytracer.h:449-453
 
-    bool have_item = false, exhausted = false, path_live = false;
+    int state = ST_IDLE;
+    bool exhausted = false;
     uint32_t pix = 0, pix_end = 0, s = 0, depth_left = 0, nb = 0;
-    V3 acc{0, 0, 0}, ro{0, 0, 0}, rd{0, 0, 1};
+    V3 acc{0, 0, 0};
+    Trav T;
+    T.cur = T_DONE;
+    T.sp = 0;
 
     for (;;) {
         // ---- refill idle lanes: ballot + prefix count, one ticket atomic per wave
-        if (!have_item && !exhausted) {
+        if (state == ST_IDLE && !exhausted) {
             const unsigned long long m = __ballot(1);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             uint32_t base = 0;
@@ -605,20 +723,18 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Ren
                 pix_end = it.pix_end;
                 s = 0;
                 acc = mk(0, 0, 0);
-                have_item = pix < pix_end;
-                path_live = false;
+                state = pix < pix_end ? ST_NEW : ST_IDLE;
                 if constexpr (MODE == RT_RNG_REFERENCE)
                     rt_minstd_seed(&rng.g, it.seed); // RaytracerThreadContext(ctx, span) :648
             } else {
                 exhausted = true;
             }
         }
-        if (__ballot(have_item) == 0ull)
+        if (__ballot(state != ST_IDLE) == 0ull)
             break;
-        if (!have_item)
-            continue;
 
-        if (!path_live) { // render_pixel loop head :621-622 + gen_ray :527-538
+        // ---- render_pixel loop head :621-622 + gen_ray :527-538
+        if (state == ST_NEW) {
             if constexpr (MODE == RT_RNG_DEVICE)
                 rt_xoshiro_seed(&rng.g, L.seed, pix, s);
             const uint32_t x = pix % L.width, y = pix / L.width;
@@ -626,21 +742,35 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Ren
             float oy = uniform_real(rng, 0.0f, 1.0f);
             float sx = (2 * ((float)(int)x + ox) / (float)L.width - 1) * L.tan_x;
             float sy = (2 * ((float)(int)y + oy) / (float)L.height - 1) * L.tan_y;
-            rd = norm(sx * cam_right - sy * cam_up + 1.0f * cam_fwd);
-            ro = cam_pos;
+            V3 rd = norm(sx * cam_right - sy * cam_up + 1.0f * cam_fwd);
             depth_left = S.ray_depth;
             nb = 0;
-            path_live = true;
+            st.cast();
+            trav_init(T, S.scene, cam_pos, rd); // ray_depth >= 1 here, so trace_ray casts (:600)
+            state = T.cur == T_DONE ? ST_READY : ST_TRAV;
         }
 
-        // ---- one trace_ray level (:593-605)
-        bool terminal = false;
-        V3 term{0, 0, 0};
-        if (depth_left == 0) {
-            terminal = true;
-        } else {
-            st.cast();
-            const Hit h = closest_hit<STATS>(S.scene, ro, rd, EPS, stk_ref, stk_d, stk_loc, st);
+        // ---- closest-hit traversal, one record per lane per step
+        for (;;) {
+            const unsigned long long tm = __ballot(state == ST_TRAV);
+            if (tm == 0ull)
+                break;
+            if (__popcll(tm) < TRAV_MIN_LANES && __ballot(state == ST_READY) != 0ull)
+                break;
+            if (state == ST_TRAV) {
+                trav_step<STATS>(T, S.scene, stk, EPS, st);
+                if (T.cur == T_DONE)
+                    state = ST_READY;
+            }
+        }
+
+        // ---- trace_ray's hit / miss branch (:602-604) and shade (:555-591) for the lanes whose traversal finished
+        if (state == ST_READY) {
+            bool terminal = false;
+            V3 term{0, 0, 0};
+            V3 nro{0, 0, 0}, nrd{0, 0, 1};
+            const Hit h = T.best;
+            const V3 ro = T.o, rd = T.d;
             if (h.k == RT_NONE) {
                 terminal = true;
                 term = ld3(S.bg) * mk(1, 1, 1); // Scene::bg_at with the 1x1 white bg (scene.h:83-89)
@@ -649,7 +779,8 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Ren
                 const Surf ii = make_surf<STATS>(S, h, rd, s_lin, s_gam, st);
                 const V3 pos = ro + rd * h.t; // ray.at(t)
                 if (!(uniform_real(rng, 0.0f, 1.0f) <= ii.color.a)) { // !coin(alpha) :559-561
-                    ro = pos;
+                    nro = pos;
+                    nrd = rd;
                 } else {
                     const float vr = pow2(rmax(ii.roughness, MIN_ROUGHNESS)); // :563-564
                     V3 dir;
@@ -686,7 +817,7 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Ren
                         } else { // mix_dist::pdf :395-407
                             float r = 0;
                             r += cos_p;
-                            r += lights_pdf<STATS>(S, pos, dir, stk_ref, st);
+                            r += lights_pdf<STATS>(S, pos, dir, stk, st);
                             MIS_p = r / 2.0f;
                         }
                         const float p = VNDF_FACTOR * VNDF_p + (1 - VNDF_FACTOR) * MIS_p;
@@ -706,43 +837,52 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Ren
                                 fold_s[3 * nb + 1] = scl.y;
                                 fold_s[3 * nb + 2] = scl.z;
                                 ++nb;
-                                ro = pos;
-                                rd = dir;
+                                nro = pos;
+                                nrd = dir;
                             }
                         }
                     }
                 }
             }
-        }
-
-        if (terminal) {
-            V3 res = term;
-            while (nb > 0) { // unwind shade() frames: emission + clr, clr = inner * scl
-                --nb;
-                V3 clr = res * mk(fold_s[3 * nb], fold_s[3 * nb + 1], fold_s[3 * nb + 2]);
-                res = mk(fold_e[3 * nb], fold_e[3 * nb + 1], fold_e[3 * nb + 2]) + clr;
+            if (!terminal) {
+                if (depth_left == 0) { // trace_ray(..., 0) returns (0,0,0) without casting (:596-598)
+                    terminal = true;
+                    term = mk(0, 0, 0);
+                } else {
+                    st.cast();
+                    trav_init(T, S.scene, nro, nrd);
+                    state = T.cur == T_DONE ? ST_READY : ST_TRAV;
+                }
             }
-            if (isnan_f(res.x)) // sanitize_nans :607-616
-                res.x = 0;
-            if (isnan_f(res.y))
-                res.y = 0;
-            if (isnan_f(res.z))
-                res.z = 0;
-            acc = acc + res;
-            st.sample();
-            path_live = false;
-            ++s;
-            if (s == L.samples) { // return res / samples :626
-                const V3 out = acc / (float)L.samples;
-                float *dst = L.fb + 3ull * pix;
-                dst[0] = out.x;
-                dst[1] = out.y;
-                dst[2] = out.z;
-                ++pix;
-                s = 0;
-                acc = mk(0, 0, 0);
-                if (pix == pix_end)
-                    have_item = false;
+            if (terminal) {
+                V3 res = term;
+                while (nb > 0) { // unwind shade() frames: emission + clr, clr = inner * scl
+                    --nb;
+                    V3 clr = res * mk(fold_s[3 * nb], fold_s[3 * nb + 1], fold_s[3 * nb + 2]);
+                    res = mk(fold_e[3 * nb], fold_e[3 * nb + 1], fold_e[3 * nb + 2]) + clr;
+                }
+                if (isnan_f(res.x)) // sanitize_nans :607-616
+                    res.x = 0;
+                if (isnan_f(res.y))
+                    res.y = 0;
+                if (isnan_f(res.z))
+                    res.z = 0;
+                acc = acc + res;
+                st.sample();
+                state = ST_NEW;
+                ++s;
+                if (s == L.samples) { // return res / samples :626
+                    const V3 out = acc / (float)L.samples;
+                    float *dst = L.fb + 3ull * pix;
+                    dst[0] = out.x;
+                    dst[1] = out.y;
+                    dst[2] = out.z;
+                    ++pix;
+                    s = 0;
+                    acc = mk(0, 0, 0);
+                    if (pix == pix_end)
+                        state = ST_IDLE;
+                }
             }
         }
     }
@@ -751,15 +891,18 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Ren
 
 // ---------------------------------------------------------------------------------------------- probe kernels
 __global__ __launch_bounds__(256) void cast_kernel(const DevScene S, const float *rays, uint32_t n, uint32_t *prim_out, float *bct_out) {
+    __shared__ uint32_t s_stack[STACK_LDS_DWORDS];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    uint32_t stk_ref[RT_MAX_STACK];
-    float stk_d[RT_MAX_STACK];
-    float stk_loc[RT_MAX_STACK];
+    StackMem stk;
+    stk.lds = s_stack + threadIdx.x;
     LaneStats<false> st;
-    V3 o = ld3(rays + 6ull * i), d = ld3(rays + 6ull * i + 3);
-    Hit h = closest_hit<false>(S.scene, o, d, EPS, stk_ref, stk_d, stk_loc, st);
+    Trav T;
+    trav_init(T, S.scene, ld3(rays + 6ull * i), ld3(rays + 6ull * i + 3));
+    while (T.cur != T_DONE)
+        trav_step<false>(T, S.scene, stk, EPS, st);
+    const Hit h = T.best;
     if (h.k == RT_NONE) {
         prim_out[i] = RT_NONE;
         bct_out[3ull * i] = bct_out[3ull * i + 1] = bct_out[3ull * i + 2] = 0.0f;
@@ -772,16 +915,19 @@ __global__ __launch_bounds__(256) void cast_kernel(const DevScene S, const float
 }
 
 __global__ __launch_bounds__(256) void light_pdf_kernel(const DevScene S, const float *rays, uint32_t n, float *pdf_out) {
+    __shared__ uint32_t s_stack[STACK_LDS_DWORDS];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    uint32_t stk_ref[RT_MAX_STACK];
+    StackMem stk;
+    stk.lds = s_stack + threadIdx.x;
     LaneStats<false> st;
     V3 o = ld3(rays + 6ull * i), d = ld3(rays + 6ull * i + 3);
-    pdf_out[i] = S.lights.n_tris ? lights_pdf<false>(S, o, d, stk_ref, st) : 0.0f;
+    pdf_out[i] = S.lights.n_tris ? lights_pdf<false>(S, o, d, stk, st) : 0.0f;
 }
 
 } // namespace
+
 
 namespace rt {
 
