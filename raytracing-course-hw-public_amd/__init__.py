@@ -39,7 +39,7 @@ from ._ctypes_abi import (
 )
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "csrc", "librt_amd.so")  # RT_AMD_LIB: tuning variants only
 _lib: Optional[C.CDLL] = None
 
 

@@ -215,6 +215,12 @@ FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions) {
         d.left = ref_of(nd.left);
         d.right = ref_of(nd.right);
         d.pad[0] = d.pad[1] = 0;
+        for (const float *bx : {d.lmin, d.lmax, d.rmin, d.rmax})
+            for (int c = 0; c < 3; ++c) {
+                const float m = std::fabs(bx[c]);
+                if (!(bx[c] == 0.0f || (m >= 7.275957614183426e-12f && m <= 1099511627776.0f)))
+                    f.fast_ok = false;
+            }
     }
     f.root = ref_of(bvh.root);
     return f;

@@ -27,6 +27,7 @@ struct FlatBvh {
     std::vector<DevNode> nodes; // inner nodes only, pre-order among inner nodes
     std::vector<DevTri> tris;   // leaf order == HostBvh::order
     uint32_t root = RT_NONE;
+    bool fast_ok = true; // all box coordinates are 0 or within [2^-37, 2^40] in magnitude
 };
 FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions);
 

@@ -74,6 +74,8 @@ struct DevBvh {
     const DevTri *tris;
     uint32_t root;   // RT_NONE (no objects at all), inner index, or RT_LEAF_FLAG|0
     uint32_t n_tris; // BVH::objects.size()
+    uint32_t fast_ok; // every node box coordinate is 0 or has magnitude in [2^-37, 2^40] (div_exact_fast precondition)
+    uint32_t pad;
 };
 
 struct DevScene {

@@ -143,9 +143,13 @@ template <class R> DEV float uniform_real(R &r, float a, float b) { return r.can
 
 // ---------------------------------------------------------------------------------------------- primitives
 // Exact quotient a/d from a precomputed r = RN(1/d): two FMA correction steps (Markstein: with r the correctly
-// rounded reciprocal and a faithful q, q + (a - d*q)*r rounds to RN(a/d); the first step makes q faithful). Valid
-// only while a, d, q and the residuals stay in the normal range — the caller checks |d| and |q| in [2^-40, 2^40] and
-// otherwise falls back to the IEEE division. 5 VALU ops instead of the ~11-op division expansion with v_rcp.
+// rounded reciprocal and a faithful q, RN(q + (a - d*q)*r) = RN(a/d); the first step makes q faithful). 5 VALU ops
+// instead of the ~11-op IEEE division expansion (v_div_scale/v_rcp/.../v_div_fixup). The residual a - d*q must be
+// exactly representable and nothing may overflow/underflow; that is guaranteed per RAY and per SCENE, not per box:
+//   * every direction component has |d_i| in [2^-40, 2^40]                                   (trav_init)
+//   * every origin component and every box coordinate is 0 or has magnitude in [2^-37, 2^40] (trav_init, host)
+// so a = box - o is 0 or a multiple of 2^-60 with |a| <= 2^41, hence q = 0 or 2^-100 <= |q| <= 2^81, all normal.
+// Rays (or scenes) outside these bounds take the reference IEEE division instead.
 DEV float div_exact_fast(float a, float d, float r) {
     float q0 = a * r;
     float e0 = __builtin_fmaf(-d, q0, a);
@@ -153,8 +157,13 @@ DEV float div_exact_fast(float a, float d, float r) {
     float e1 = __builtin_fmaf(-d, q1, a);
     return __builtin_fmaf(e1, r, q1);
 }
-constexpr float RANGE_LO = 9.094947017729282e-13f; // 2^-40
-constexpr float RANGE_HI = 1099511627776.0f;       // 2^40
+constexpr float RANGE_LO = 9.094947017729282e-13f;  // 2^-40
+constexpr float RANGE_HI = 1099511627776.0f;        // 2^40
+constexpr float ORIGIN_LO = 7.275957614183426e-12f; // 2^-37
+DEV bool coord_in_fast_range(float c) { // 0, or 2^-37 <= |c| <= 2^40 (false for NaN / inf)
+    const float m = __builtin_fabsf(c);
+    return (c == 0.0f) | ((m >= ORIGIN_LO) & (m <= RANGE_HI));
+}
 
 // intersect(ray, aabb, min_dst) bvh.h:137-152, reference form: IEEE division, std::min/max operand order kept by
 // explicit selects, component reductions as std::max_element / std::min_element (first extremum, geometry.h:42-50).
@@ -180,21 +189,14 @@ DEV bool box_hit_exact(V3 bmin, V3 bmax, V3 o, V3 d, float min_dst, float &dist)
     return false;
 }
 
-// Same slab test on the fast path: the six quotients come from div_exact_fast; when all of them are finite, non-zero
-// and inside [2^-40, 2^40] (so: no NaN, no +-0, no inf) v_min/v_max agree with the select forms bit for bit. `ok`
-// reports whether that held; if not the caller redoes the box with box_hit_exact.
-DEV bool box_hit_fast(V3 bmin, V3 bmax, V3 o, V3 d, V3 r, float min_dst, float &dist, bool &ok) {
+// Same slab test on the fast path: the six quotients come from div_exact_fast and are the correctly rounded finite
+// quotients (see above), so there is no NaN and no infinity among them and v_min/v_max agree with the reference's
+// select forms up to the sign of a zero, which cannot reach the result: t_min/t_max are only compared, and
+// max(t_min, min_dst) with min_dst = 1e-4 > 0 never returns a zero.
+DEV bool box_hit_fast(V3 bmin, V3 bmax, V3 o, V3 d, V3 r, float min_dst, float &dist) {
     V3 a1 = bmin - o, a2 = bmax - o;
     float q1x = div_exact_fast(a1.x, d.x, r.x), q1y = div_exact_fast(a1.y, d.y, r.y), q1z = div_exact_fast(a1.z, d.z, r.z);
     float q2x = div_exact_fast(a2.x, d.x, r.x), q2y = div_exact_fast(a2.y, d.y, r.y), q2z = div_exact_fast(a2.z, d.z, r.z);
-    float lo = fminf(fminf(fminf(__builtin_fabsf(q1x), __builtin_fabsf(q1y)), fminf(__builtin_fabsf(q1z), __builtin_fabsf(q2x))),
-                     fminf(__builtin_fabsf(q2y), __builtin_fabsf(q2z)));
-    float hi = fmaxf(fmaxf(fmaxf(__builtin_fabsf(q1x), __builtin_fabsf(q1y)), fmaxf(__builtin_fabsf(q1z), __builtin_fabsf(q2x))),
-                     fmaxf(__builtin_fabsf(q2y), __builtin_fabsf(q2z)));
-    // NaNs: fminf/fmaxf drop them, so test every |q| <= hi chain is not enough; a NaN quotient needs a NaN/inf/0
-    // input, which also shows up as lo == 0 or hi == inf except for NaN inputs themselves -> check q == q below.
-    bool no_nan = (q1x == q1x) & (q1y == q1y) & (q1z == q1z) & (q2x == q2x) & (q2y == q2y) & (q2z == q2z);
-    ok = no_nan & (lo >= RANGE_LO) & (hi <= RANGE_HI);
     float t_min = fmaxf(fmaxf(fminf(q1x, q2x), fminf(q1y, q2y)), fminf(q1z, q2z));
     float t_max = fminf(fminf(fmaxf(q1x, q2x), fmaxf(q1y, q2y)), fmaxf(q1z, q2z));
     dist = fmaxf(t_min, min_dst);
@@ -247,7 +249,10 @@ struct Hit {
 // positions live in LDS, one column per thread (bank = thread % 32: conflict free whatever the lanes' depths);
 // deeper positions fall back to per-lane scratch. sp counts only ancestors whose BOTH children were hit, so the LDS
 // part serves almost every access (DESIGN.md "traversal stack").
-constexpr int LDS_DEPTH = 12;
+#ifndef RT_LDS_DEPTH
+#define RT_LDS_DEPTH 12
+#endif
+constexpr int LDS_DEPTH = RT_LDS_DEPTH;
 struct StackMem {
     uint32_t *lds; // [3][LDS_DEPTH][256] dwords, this thread's column starts at lds + threadIdx.x
     uint32_t ov_ref[RT_MAX_STACK - LDS_DEPTH];
@@ -302,7 +307,7 @@ struct Trav {
     int sp;
     float t_loc;
     Hit best;
-    bool fast; // every |d_i| in [2^-40, 2^40]
+    bool fast; // div_exact_fast is valid for this ray (see its comment)
 };
 DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
     T.o = o;
@@ -310,7 +315,8 @@ DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
     T.r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float lo = fminf(fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
     float hi = fmaxf(fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
-    T.fast = (d.x == d.x) & (d.y == d.y) & (d.z == d.z) & (lo >= RANGE_LO) & (hi <= RANGE_HI);
+    T.fast = (bvh.fast_ok != 0u) & (d.x == d.x) & (d.y == d.y) & (d.z == d.z) & (lo >= RANGE_LO) & (hi <= RANGE_HI) & coord_in_fast_range(o.x) &
+             coord_in_fast_range(o.y) & coord_in_fast_range(o.z);
     T.cur = (bvh.root == RT_NONE || bvh.n_tris == 0) ? T_DONE : bvh.root;
     T.sp = 0;
     T.t_loc = RT_NAN;
@@ -330,12 +336,10 @@ template <bool STATS> DEV void trav_step(Trav &T, const DevBvh &bvh, StackMem &s
         const uint32_t left = __float_as_uint(r3.x), right = __float_as_uint(r3.y);
         float dl, dr;
         bool hl, hr;
-        bool okl = false, okr = false;
         if (T.fast) {
-            hl = box_hit_fast(lmin, lmax, T.o, T.d, T.r, min_dst, dl, okl);
-            hr = box_hit_fast(rmn, rmx, T.o, T.d, T.r, min_dst, dr, okr);
-        }
-        if (!(okl & okr)) { // rare: a quotient was 0 / inf / NaN / out of range -> reference arithmetic
+            hl = box_hit_fast(lmin, lmax, T.o, T.d, T.r, min_dst, dl);
+            hr = box_hit_fast(rmn, rmx, T.o, T.d, T.r, min_dst, dr);
+        } else { // rare ray: a direction/origin component is 0-adjacent, huge or NaN -> reference arithmetic
             hl = box_hit_exact(lmin, lmax, T.o, T.d, min_dst, dl);
             hr = box_hit_exact(rmn, rmx, T.o, T.d, min_dst, dr);
         }
@@ -678,10 +682,16 @@ enum { ST_IDLE = 0, ST_NEW = 1, ST_TRAV = 2, ST_READY = 3 };
 // When fewer than TRAV_MIN_LANES lanes of the wave are still traversing and others wait to be shaded, the traversal
 // loop is left: the finished lanes shade, generate their next ray and re-enter together with the stragglers, which
 // resume where they stopped. Keeps the 64-wide wave dense through the heavy-tailed traversal lengths.
-constexpr int TRAV_MIN_LANES = 40;
+#ifndef RT_TRAV_MIN_LANES
+#define RT_TRAV_MIN_LANES 40
+#endif
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 1
+#endif
+constexpr int TRAV_MIN_LANES = RT_TRAV_MIN_LANES;
 
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(256) void render_kernel(const DevScene S, const RenderLaunch L) {
+__global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const DevScene S, const RenderLaunch L) {
     __shared__ float s_lin[256];
     __shared__ float s_gam[256];
     __shared__ uint32_t s_stack[STACK_LDS_DWORDS];

@@ -62,7 +62,7 @@ struct rt_scene {
     float *d_fb = nullptr;
     size_t fb_capacity = 0; // floats
     int num_cus = 0;
-    int blocks_per_cu = 4;
+    int blocks_per_cu = 8; // upper bound on resident 256-thread blocks per CU; surplus blocks find the ticket exhausted
     ~rt_scene() {
         (void)hipSetDevice(device);
         for (void *p : owned)
@@ -193,6 +193,7 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
             return rc;
         b.root = flat[w].root;
         b.n_tris = (uint32_t)flat[w].tris.size();
+        b.fast_ok = flat[w].fast_ok ? 1u : 0u;
     }
     if ((rc = upload(attrs, &D.attrs, s->owned)) != RT_OK)
         return rc;

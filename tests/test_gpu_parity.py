@@ -69,6 +69,25 @@ def test_closest_hit_degenerate_rays(pairs):
     assert np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
 
 
+def test_closest_hit_fast_division_boundaries(pairs):
+    """Rays on both sides of the exact-reciprocal-division preconditions (rt_kernels.hip div_exact_fast): origin
+    components that are 0, tiny (1e-30), huge (1e15); direction components that are 0, 1e-20 or dominate."""
+    dev, orc, sc = pairs["room_plain"]
+    rays = random_rays(sc, 6000, seed=303)
+    rng = np.random.default_rng(8)
+    specials_o = np.array([0.0, 1e-30, -1e-30, 1e-13, 1e15, 4.0, -20.0, 16.0], dtype=np.float32)
+    specials_d = np.array([0.0, 1e-20, -1e-20, 1e-13, 1.0], dtype=np.float32)
+    for i in range(3000):
+        rays[i, rng.integers(0, 3)] = rng.choice(specials_o)
+        if i % 2:
+            rays[i, 3 + rng.integers(0, 3)] = rng.choice(specials_d)
+    gp, gb = dev.cast_rays(rays)
+    op, ob = orc.cast_rays(rays)
+    assert np.array_equal(gp, op)
+    assert np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+    assert (gp != 0xFFFFFFFF).sum() > 2000
+
+
 @pytest.mark.parametrize("name", ["room_plain", "room_textured", "boxes"])
 def test_light_pdf_bit_exact(pairs, name):
     dev, orc, sc = pairs[name]

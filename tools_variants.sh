@@ -1,0 +1,13 @@
+#!/usr/bin/env bash
+# tools_variants.sh — build tuning variants of librt_amd.so into csrc/variants/<name>.so:  name:"-Dflags"
+# (development aid for kernel tuning; the shipped library is csrc/librt_amd.so)
+set -e
+cd "$(dirname "$0")/raytracing-course-hw-public_amd/csrc"
+mkdir -p variants
+for spec in "$@"; do
+  name="${spec%%:*}"; flags="${spec#*:}"
+  /opt/rocm/bin/hipcc -std=c++20 -O3 -ffp-contract=off -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 $flags -c rt_kernels.hip -o variants/$name.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/$name.so host/film.o host/png_decode.o host/gltf_loader.o bvh_build.o rt_scene.o variants/$name.o -lz
+  rm -f variants/$name.o
+  echo "built $name ($flags)"
+done
