@@ -126,6 +126,23 @@ template <> struct LaneStats<true> {
     }
 };
 
+// Development-only wave-level execution census (-DRT_DIAG, tools_variants.sh): how often each section of the
+// persistent loop runs and with how many active lanes. Reuses the DevStats words; never compiled into the product.
+#ifdef RT_DIAG
+__device__ DevStats *g_diag = nullptr;
+DEV void diag_add(int slot, unsigned long long v) {
+    const unsigned long long m = __ballot(1);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (rank == 0 && g_diag)
+        atomicAdd(reinterpret_cast<unsigned long long *>(g_diag) + slot, v);
+}
+#define DIAG(slot, v) diag_add(slot, v)
+#define DIAG_LANES(slot) diag_add(slot, (unsigned long long)__popcll(__ballot(1)))
+#else
+#define DIAG(slot, v) do { } while (0)
+#define DIAG_LANES(slot) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------- RNG policy
 template <int MODE> struct Rng;
 template <> struct Rng<RT_RNG_DEVICE> {
@@ -205,21 +222,28 @@ DEV bool box_hit_fast(V3 bmin, V3 bmax, V3 o, V3 d, V3 r, float min_dst, float &
 
 // intersect_ray_triangle + intersect(ray, triangle, min_dst) bvh.h:36-65 (Cramer; xs = (b, c, t)).
 // det(c1,c2,c3) = dot(c1, crs(c2,c3)) (geometry.h:26-29); crs(u, -d) is shared by two determinants.
-// Division-free early reject: a numerator whose sign certainly differs from the denominator's (|n| > 2^-60,
-// |den| < 2^60, so the quotient cannot round to -0) makes xs.x >= 0, xs.y >= 0 or xs.z >= min_dst false without
-// computing the quotient. Everything else takes the reference's three IEEE divisions.
-DEV bool surely_negative(float n, float den) {
-    const uint32_t sn = __float_as_uint(n) ^ __float_as_uint(den);
-    return (sn >> 31) & (__builtin_fabsf(n) > 8.673617379884035e-19f) & (__builtin_fabsf(n) < RT_INF);
-}
+// Division-free rejection filter. With D = |den| in [2^-60, 2^60] and sign-adjusted numerators n' = n * sign(den)
+// (so the exact quotients are X = nx'/D, Y = ny'/D, Z = nz'/D) a triangle CERTAINLY fails the reference's test
+//     xs.x >= 0 && xs.y >= 0 && xs.x + xs.y <= 1 && xs.z >= min_dst          (bvh.h:59-60, xs = RN(n/den))
+// when  nx' < -2^-60  or  ny' < -2^-60           (X or Y < -2^-120: the rounded quotient is negative, not -0)
+//   or  nx' + ny' > D * (1 + 2^-20)               (X + Y > 1 + 2^-20: beyond the three roundings, ~3 * 2^-24)
+//   or  nz' < D * min_dst * (1 - 2^-20)           (Z < min_dst beyond the rounding of RN(Z))
+// Anything else ("maybe") takes the reference's three IEEE divisions and its exact comparisons, so the filter only
+// removes work, never changes an outcome. NaN/inf operands make every comparison false -> "maybe".
 DEV bool tri_hit(V3 ta, V3 av, V3 au, V3 o, V3 d, float min_dst, V3 &xs_out) {
     V3 at = -d;
     V3 y = o - ta;
     V3 c_ut = crs(au, at);
     float den = dot(av, c_ut);
     float nx = dot(y, c_ut), ny = dot(av, crs(y, at)), nz = dot(av, crs(au, y));
-    const bool den_ok = (__builtin_fabsf(den) < 1.152921504606847e18f) & (den != 0.0f); // finite, |den| < 2^60
-    if (den_ok & (surely_negative(nx, den) | surely_negative(ny, den) | surely_negative(nz, den)))
+    const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+    const float D = __builtin_fabsf(den);
+    const float nxs = __uint_as_float(__float_as_uint(nx) ^ sgn), nys = __uint_as_float(__float_as_uint(ny) ^ sgn),
+                nzs = __uint_as_float(__float_as_uint(nz) ^ sgn);
+    const bool d_ok = (D >= 8.673617379884035e-19f) & (D <= 1.152921504606847e18f); // 2^-60 .. 2^60
+    const bool miss = (nxs < -8.673617379884035e-19f) | (nys < -8.673617379884035e-19f) | (nxs + nys > D * 1.00000095367431640625f) |
+                      (nzs < D * (min_dst * 0.99999904632568359375f));
+    if (d_ok & miss)
         return false;
     V3 xs = V3{nx, ny, nz} / den;
     if (xs.x >= 0 && xs.y >= 0 && xs.x + xs.y <= 1 && xs.z >= min_dst) {
@@ -308,6 +332,9 @@ struct Trav {
     float t_loc;
     Hit best;
     bool fast; // div_exact_fast is valid for this ray (see its comment)
+    // newest frame (stack position sp-1) cached in registers: a pop followed by a node visit never waits for LDS
+    uint32_t top_ref;
+    float top_d, top_loc;
 };
 DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
     T.o = o;
@@ -336,10 +363,13 @@ template <bool STATS> DEV void trav_step(Trav &T, const DevBvh &bvh, StackMem &s
         const uint32_t left = __float_as_uint(r3.x), right = __float_as_uint(r3.y);
         float dl, dr;
         bool hl, hr;
+        DIAG(2, 1);
+        DIAG_LANES(3);
         if (T.fast) {
             hl = box_hit_fast(lmin, lmax, T.o, T.d, T.r, min_dst, dl);
             hr = box_hit_fast(rmn, rmx, T.o, T.d, T.r, min_dst, dr);
         } else { // rare ray: a direction/origin component is 0-adjacent, huge or NaN -> reference arithmetic
+            DIAG(6, 1);
             hl = box_hit_exact(lmin, lmax, T.o, T.d, min_dst, dl);
             hr = box_hit_exact(rmn, rmx, T.o, T.d, min_dst, dr);
         }
@@ -351,7 +381,11 @@ template <bool STATS> DEV void trav_step(Trav &T, const DevBvh &bvh, StackMem &s
                 far = left;
                 dfar = dl;
             }
-            stk.push(T.sp, far, dfar, T.t_loc);
+            if (T.sp > 0)
+                stk.push(T.sp - 1, T.top_ref, T.top_d, T.top_loc); // spill the previous top
+            T.top_ref = far;
+            T.top_d = dfar;
+            T.top_loc = T.t_loc;
             ++T.sp;
             T.t_loc = RT_NAN;
             T.cur = near;
@@ -363,6 +397,8 @@ template <bool STATS> DEV void trav_step(Trav &T, const DevBvh &bvh, StackMem &s
             T.cur = T_POP;
         }
     } else {
+        DIAG(4, 1);
+        DIAG_LANES(5);
         // DevTri: a.xyz v.xyz u.xyz prim flags pad
         const uint32_t flags = __float_as_uint(r2.z);
         if (flags & 2u)
@@ -381,14 +417,17 @@ template <bool STATS> DEV void trav_step(Trav &T, const DevBvh &bvh, StackMem &s
         T.cur = (flags & 1u) ? T_POP : T.cur + 1;
     }
     while (T.cur == T_POP) {
+        DIAG(7, 1);
+        DIAG_LANES(8);
         if (T.sp == 0) {
             T.cur = T_DONE;
             break;
         }
         --T.sp;
-        uint32_t ref;
-        float dfar, saved;
-        stk.pop(T.sp, ref, dfar, saved);
+        const uint32_t ref = T.top_ref;
+        const float dfar = T.top_d, saved = T.top_loc;
+        if (T.sp > 0)
+            stk.pop(T.sp - 1, T.top_ref, T.top_d, T.top_loc); // refill the register copy; consumed at the next pop
         const float t_near = T.t_loc;
         T.t_loc = fminf(saved, t_near);
         if (!(t_near <= dfar)) // !has || t_near > d_far (bvh.h:221)
@@ -686,7 +725,7 @@ enum { ST_IDLE = 0, ST_NEW = 1, ST_TRAV = 2, ST_READY = 3 };
 #define RT_TRAV_MIN_LANES 40
 #endif
 #ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 1
+#define RT_WAVES_PER_SIMD 4 /* <= 128 VGPRs: 4 waves/SIMD measured fastest (tools_sweep.sh) */
 #endif
 constexpr int TRAV_MIN_LANES = RT_TRAV_MIN_LANES;
 
@@ -699,6 +738,10 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const De
     s_gam[threadIdx.x] = S.lut_gamma[threadIdx.x];
     __syncthreads();
 
+#ifdef RT_DIAG
+    if (STATS && threadIdx.x == 0 && blockIdx.x == 0)
+        g_diag = L.stats;
+#endif
     LaneStats<STATS> st;
     Rng<MODE> rng;
     StackMem stk;
@@ -767,6 +810,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const De
                 break;
             if (__popcll(tm) < TRAV_MIN_LANES && __ballot(state == ST_READY) != 0ull)
                 break;
+            DIAG(0, 1);
+            DIAG(1, (unsigned long long)__popcll(tm));
             if (state == ST_TRAV) {
                 trav_step<STATS>(T, S.scene, stk, EPS, st);
                 if (T.cur == T_DONE)
@@ -775,7 +820,10 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const De
         }
 
         // ---- trace_ray's hit / miss branch (:602-604) and shade (:555-591) for the lanes whose traversal finished
+        DIAG(11, 1);
         if (state == ST_READY) {
+            DIAG(9, 1);
+            DIAG_LANES(10);
             bool terminal = false;
             V3 term{0, 0, 0};
             V3 nro{0, 0, 0}, nrd{0, 0, 1};
@@ -896,7 +944,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const De
             }
         }
     }
+#ifndef RT_DIAG
     st.flush(L.stats);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- probe kernels
