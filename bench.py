@@ -93,29 +93,14 @@ def main() -> None:
     t_create = time.time() - t0
 
     block = SHARD_ROWS * W
+    sharding = importlib.import_module("raytracing-course-hw-public_amd.sharding")
     fb = torch.zeros(n_pix * 3, dtype=torch.float32, device=device)
-    n_blocks = (n_pix + block - 1) // block
-    # gather plumbing: equal-sized padded slabs of this rank's blocks -> rank 0
-    my_blocks = list(range(rank, n_blocks, world))
-    max_blocks = (n_blocks + world - 1) // world
-    slab = torch.zeros(max_blocks * block * 3, dtype=torch.float32, device=device)
-    gathered = [torch.empty_like(slab) for _ in range(world)] if (world > 1 and rank == 0) else None
-    full = torch.zeros(n_blocks * block * 3, dtype=torch.float32, device=device) if rank == 0 else None
+    gather = sharding.FramebufferGather(n_pix, block, rank, world, device)
+    my_pixels = sharding.shard_pixels(n_pix, block, rank, world)
 
     def step():
         _, st = dev.run_raytracer(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr())
-        if world > 1:
-            # compact this rank's interleaved blocks into a slab, RCCL gather over xGMI, de-interleave on rank 0
-            padded = torch.zeros(n_blocks * block * 3, dtype=torch.float32, device=device)
-            padded[: n_pix * 3] = fb
-            mine = padded.view(n_blocks, block * 3)[rank::world]
-            slab[: mine.numel()] = mine.reshape(-1)
-            dist.gather(slab, gathered, dst=0)
-            if rank == 0:
-                fv = full.view(n_blocks, block * 3)
-                for r in range(world):
-                    nb = len(range(r, n_blocks, world))
-                    fv[r::world] = gathered[r][: nb * block * 3].view(nb, block * 3)
+        gather.gather(fb)  # N > 1: RCCL gather of this rank's interleaved blocks to rank 0 (no-op at N = 1)
         return st
 
     def sync():
@@ -143,7 +128,6 @@ def main() -> None:
 
     # ---- roofline of the dominant (only) kernel: algorithmic bytes per launch / average launch duration
     _, cst = dev.run_raytracer(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr(), counters=True)
-    my_pixels = sum(min((b + 1) * block, n_pix) - b * block for b in my_blocks)
     bytes_per_launch = algorithmic_bytes(cst, my_pixels)
     avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
     achieved = bytes_per_launch / avg_kernel_s / 1e9

