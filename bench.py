@@ -47,6 +47,26 @@ def algorithmic_bytes(st: dict, n_pixels: int) -> float:
     return float(trav + light + shade + 12 * n_pixels)
 
 
+def effective_cores() -> int:
+    """Host threads this process may really use: CPU affinity capped by the cgroup CPU quota (the GPU box exposes 256
+    logical CPUs but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,7 +178,7 @@ def main() -> None:
         import oracle
 
         orc = oracle.OracleScene(scene)
-        cores = os.cpu_count() or 1
+        cores = effective_cores()
         # bounded sample of the same workload: every 16th 256-pixel span of the same image, reference RNG + libm
         # (the reference CPU path, raytracer.h:636-662), SPP chosen from a short probe to land near --cpu-seconds.
         share = 16

@@ -129,8 +129,11 @@ typedef struct rt_params {
 enum {
     RT_FLAG_NONE = 0,
     RT_FLAG_DEVICE_FB = 1, /* fb_rgb is a device pointer (HBM resident); no D2H copy */
-    RT_FLAG_COUNTERS = 2   /* run the instrumented kernel variant and fill the event counters of rt_stats
+    RT_FLAG_COUNTERS = 2,  /* run the instrumented kernel variant and fill the event counters of rt_stats
                               (slower; timing fields are filled whenever `stats` is non-NULL) */
+    RT_FLAG_MEGAKERNEL = 4 /* RT_RNG_DEVICE only: use the persistent one-lane-per-pixel megakernel instead of the
+                              wavefront pipeline (same image bit for bit; kept as a cross-check. RT_RNG_REFERENCE
+                              always uses the megakernel: its RNG stream is sequential per 256-pixel span) */
 };
 
 /* Per-render statistics (optional out-parameter). Counters are layout independent event counts in the

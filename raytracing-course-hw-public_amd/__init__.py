@@ -23,6 +23,7 @@ from ._ctypes_abi import (
     HOST_PROTOTYPES,
     RT_FLAG_COUNTERS,
     RT_FLAG_DEVICE_FB,
+    RT_FLAG_MEGAKERNEL,
     RT_OK,
     RT_RNG_DEVICE,
     RT_RNG_REFERENCE,
@@ -140,11 +141,12 @@ class DeviceScene:
         out: Optional[np.ndarray] = None,
         device_fb: int = 0,
         counters: bool = False,
+        megakernel: bool = False,
     ):
         """run_raytracer(scene, image) (raytracer.h:629): returns (linear float framebuffer (H,W,3), stats dict).
         With `device_fb` (a device pointer) the framebuffer stays in HBM and None is returned for it.
         `counters=True` runs the instrumented kernel variant and fills the event counters of the stats."""
-        p = RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block, RT_FLAG_COUNTERS if counters else 0)
+        p = RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block, (RT_FLAG_COUNTERS if counters else 0) | (RT_FLAG_MEGAKERNEL if megakernel else 0))
         st = RtStats()
         if device_fb:
             p.flags |= RT_FLAG_DEVICE_FB

@@ -15,6 +15,7 @@ RT_RNG_DEVICE = 0
 RT_RNG_REFERENCE = 1
 RT_FLAG_DEVICE_FB = 1
 RT_FLAG_COUNTERS = 2
+RT_FLAG_MEGAKERNEL = 4
 
 RT_OK = 0
 ERROR_NAMES = {

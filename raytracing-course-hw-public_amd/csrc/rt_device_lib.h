@@ -1,0 +1,770 @@
+// rt_device_lib.h — device-side building blocks shared by the render kernels (rt_kernels.hip: persistent megakernel
+// + probe kernels; rt_wavefront.hip: the wavefront pipeline): float3 algebra with the reference's operation order,
+// exact slab / triangle tests, the resumable BVH traversal step, the light-pdf traversal, texture sampling, the shading
+// record, sampling distributions and the BRDF. Reference citations are next to each function.
+//
+// Arithmetic contract: IEEE binary32, correctly rounded / and sqrt, no FMA contraction (-ffp-contract=off); FMA only
+// where written explicitly (div_exact_fast). std::min/std::max operand order is reproduced by explicit selects.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_abi.h"
+#include "../../include/rt_devspec.h"
+#include "rt_device_types.h"
+
+namespace {
+
+constexpr float EPS = 1e-4;               // config.h:15
+constexpr float MIN_ROUGHNESS = 0.04f;    // config.h:20
+constexpr float VNDF_FACTOR = 1.0f / 3;   // config.h:26
+constexpr float PI_F = 3.14159265358979323846f;
+#define RT_INF __builtin_inff()
+#define RT_NAN __builtin_nanf("")
+
+#define DEV __device__ __forceinline__
+
+struct V3 {
+    float x, y, z;
+};
+DEV V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+DEV V3 ld3(const float *p) { return V3{p[0], p[1], p[2]}; }
+DEV V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+DEV V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+DEV V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+DEV V3 operator/(V3 a, V3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+DEV V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+DEV V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+DEV V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+DEV V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+DEV V3 operator-(float s, V3 a) { return {s - a.x, s - a.y, s - a.z}; }
+DEV V3 operator-(V3 a, float s) { return {a.x - s, a.y - s, a.z - s}; }
+DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV float len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+DEV float len(V3 a) { return __builtin_sqrtf(len2(a)); }
+DEV V3 crs(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; } // geometry.h:18-24
+DEV V3 norm(V3 v) { return v / len(v); }                                                                   // geometry.h:31-34
+DEV float rmin(float a, float b) { return (b < a) ? b : a; } // std::min(a,b)
+DEV float rmax(float a, float b) { return (a < b) ? b : a; } // std::max(a,b)
+DEV V3 transform3(V3 l, V3 x, V3 y, V3 z) { return l.x * x + l.y * y + l.z * z; } // geometry.h:355-359
+DEV float pow2(float x) { return x * x; }
+DEV float pow5(float x) { // raytracer.h:28-38, p = 5
+    float x2 = x * x;
+    return x * ((x2 * x2) * 1.0f);
+}
+DEV bool isnan_f(float x) { return x != x; }
+
+struct C4 {
+    float r, g, b, a;
+};
+DEV C4 operator*(float s, C4 c) { return {s * c.r, s * c.g, s * c.b, s * c.a}; }
+DEV C4 operator+(C4 a, C4 b) { return {a.r + b.r, a.g + b.g, a.b + b.b, a.a + b.a}; }
+DEV C4 operator*(C4 a, C4 b) { return {a.r * b.r, a.g * b.g, a.b * b.b, a.a * b.a}; }
+
+// ---------------------------------------------------------------------------------------------- counters
+template <bool ON> struct LaneStats;
+template <> struct LaneStats<false> {
+    DEV void cast() {}
+    DEV void node() {}
+    DEV void box(uint32_t) {}
+    DEV void tri() {}
+    DEV void shaded() {}
+    DEV void lq() {}
+    DEV void lnode() {}
+    DEV void lbox(uint32_t) {}
+    DEV void ltri() {}
+    DEV void lhit() {}
+    DEV void texels(uint32_t) {}
+    DEV void sample() {}
+    DEV void flush(DevStats *) {}
+};
+template <> struct LaneStats<true> {
+    unsigned long long c_cast = 0, c_node = 0, c_box = 0, c_tri = 0, c_shaded = 0, c_lq = 0, c_lnode = 0, c_lbox = 0, c_ltri = 0, c_lhit = 0,
+                       c_tex = 0, c_sample = 0;
+    DEV void cast() { ++c_cast; }
+    DEV void node() { ++c_node; }
+    DEV void box(uint32_t n) { c_box += n; }
+    DEV void tri() { ++c_tri; }
+    DEV void shaded() { ++c_shaded; }
+    DEV void lq() { ++c_lq; }
+    DEV void lnode() { ++c_lnode; }
+    DEV void lbox(uint32_t n) { c_lbox += n; }
+    DEV void ltri() { ++c_ltri; }
+    DEV void lhit() { ++c_lhit; }
+    DEV void texels(uint32_t n) { c_tex += n; }
+    DEV void sample() { ++c_sample; }
+    DEV void flush(DevStats *s) {
+        if (!s)
+            return;
+        atomicAdd(&s->casts, c_cast);
+        atomicAdd(&s->nodes, c_node);
+        atomicAdd(&s->box_tests, c_box);
+        atomicAdd(&s->tri_tests, c_tri);
+        atomicAdd(&s->shaded, c_shaded);
+        atomicAdd(&s->lq, c_lq);
+        atomicAdd(&s->lnodes, c_lnode);
+        atomicAdd(&s->lbox, c_lbox);
+        atomicAdd(&s->ltri, c_ltri);
+        atomicAdd(&s->lhits, c_lhit);
+        atomicAdd(&s->texels, c_tex);
+        atomicAdd(&s->samples, c_sample);
+    }
+};
+
+// Development-only wave-level execution census (-DRT_DIAG, tools_variants.sh): how often each section of the
+// persistent loop runs and with how many active lanes. Reuses the DevStats words; never compiled into the product.
+#ifdef RT_DIAG
+__device__ DevStats *g_diag = nullptr;
+DEV void diag_add(int slot, unsigned long long v) {
+    const unsigned long long m = __ballot(1);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (rank == 0 && g_diag)
+        atomicAdd(reinterpret_cast<unsigned long long *>(g_diag) + slot, v);
+}
+#define DIAG(slot, v) diag_add(slot, v)
+#define DIAG_LANES(slot) diag_add(slot, (unsigned long long)__popcll(__ballot(1)))
+#else
+#define DIAG(slot, v) do { } while (0)
+#define DIAG_LANES(slot) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------- RNG policy
+template <int MODE> struct Rng;
+template <> struct Rng<RT_RNG_DEVICE> {
+    rt_xoshiro g;
+    DEV float canonical() { return rt_xoshiro_canonical(&g); }
+    DEV uint32_t below(uint32_t n) { return rt_xoshiro_below(&g, n); }
+};
+template <> struct Rng<RT_RNG_REFERENCE> {
+    rt_minstd g;
+    DEV float canonical() { return rt_minstd_canonical(&g); }
+    DEV uint32_t below(uint32_t n) { return rt_minstd_below(&g, n); }
+};
+// std::uniform_real_distribution<float>(a, b)(rng) = canonical * (b - a) + a
+template <class R> DEV float uniform_real(R &r, float a, float b) { return r.canonical() * (b - a) + a; }
+
+// ---------------------------------------------------------------------------------------------- primitives
+// Exact quotient a/d from a precomputed r = RN(1/d): two FMA correction steps (Markstein: with r the correctly
+// rounded reciprocal and a faithful q, RN(q + (a - d*q)*r) = RN(a/d); the first step makes q faithful). 5 VALU ops
+// instead of the ~11-op IEEE division expansion (v_div_scale/v_rcp/.../v_div_fixup). The residual a - d*q must be
+// exactly representable and nothing may overflow/underflow; that is guaranteed per RAY and per SCENE, not per box:
+//   * every direction component has |d_i| in [2^-40, 2^40]                                   (trav_init)
+//   * every origin component and every box coordinate is 0 or has magnitude in [2^-37, 2^40] (trav_init, host)
+// so a = box - o is 0 or a multiple of 2^-60 with |a| <= 2^41, hence q = 0 or 2^-100 <= |q| <= 2^81, all normal.
+// Rays (or scenes) outside these bounds take the reference IEEE division instead.
+DEV float div_exact_fast(float a, float d, float r) {
+    float q0 = a * r;
+    float e0 = __builtin_fmaf(-d, q0, a);
+    float q1 = __builtin_fmaf(e0, r, q0);
+    float e1 = __builtin_fmaf(-d, q1, a);
+    return __builtin_fmaf(e1, r, q1);
+}
+constexpr float RANGE_LO = 9.094947017729282e-13f;  // 2^-40
+constexpr float RANGE_HI = 1099511627776.0f;        // 2^40
+constexpr float ORIGIN_LO = 7.275957614183426e-12f; // 2^-37
+DEV bool coord_in_fast_range(float c) { // 0, or 2^-37 <= |c| <= 2^40 (false for NaN / inf)
+    const float m = __builtin_fabsf(c);
+    return (c == 0.0f) | ((m >= ORIGIN_LO) & (m <= RANGE_HI));
+}
+
+// intersect(ray, aabb, min_dst) bvh.h:137-152, reference form: IEEE division, std::min/max operand order kept by
+// explicit selects, component reductions as std::max_element / std::min_element (first extremum, geometry.h:42-50).
+DEV bool box_hit_exact(V3 bmin, V3 bmax, V3 o, V3 d, float min_dst, float &dist) {
+    V3 i1 = (bmin - o) / d;
+    V3 i2 = (bmax - o) / d;
+    V3 mn = {rmin(i1.x, i2.x), rmin(i1.y, i2.y), rmin(i1.z, i2.z)};
+    V3 mx = {rmax(i1.x, i2.x), rmax(i1.y, i2.y), rmax(i1.z, i2.z)};
+    float t_min = mn.x;
+    if (t_min < mn.y)
+        t_min = mn.y;
+    if (t_min < mn.z)
+        t_min = mn.z;
+    float t_max = mx.x;
+    if (mx.y < t_max)
+        t_max = mx.y;
+    if (mx.z < t_max)
+        t_max = mx.z;
+    if (t_min <= t_max && t_max >= min_dst) {
+        dist = rmax(t_min, min_dst);
+        return true;
+    }
+    return false;
+}
+
+// Same slab test on the fast path: the six quotients come from div_exact_fast and are the correctly rounded finite
+// quotients (see above), so there is no NaN and no infinity among them and v_min/v_max agree with the reference's
+// select forms up to the sign of a zero, which cannot reach the result: t_min/t_max are only compared, and
+// max(t_min, min_dst) with min_dst = 1e-4 > 0 never returns a zero.
+DEV bool box_hit_fast(V3 bmin, V3 bmax, V3 o, V3 d, V3 r, float min_dst, float &dist) {
+    V3 a1 = bmin - o, a2 = bmax - o;
+    float q1x = div_exact_fast(a1.x, d.x, r.x), q1y = div_exact_fast(a1.y, d.y, r.y), q1z = div_exact_fast(a1.z, d.z, r.z);
+    float q2x = div_exact_fast(a2.x, d.x, r.x), q2y = div_exact_fast(a2.y, d.y, r.y), q2z = div_exact_fast(a2.z, d.z, r.z);
+    float t_min = fmaxf(fmaxf(fminf(q1x, q2x), fminf(q1y, q2y)), fminf(q1z, q2z));
+    float t_max = fminf(fminf(fmaxf(q1x, q2x), fmaxf(q1y, q2y)), fmaxf(q1z, q2z));
+    dist = fmaxf(t_min, min_dst);
+    return (t_min <= t_max) & (t_max >= min_dst);
+}
+
+// intersect_ray_triangle + intersect(ray, triangle, min_dst) bvh.h:36-65 (Cramer; xs = (b, c, t)).
+// det(c1,c2,c3) = dot(c1, crs(c2,c3)) (geometry.h:26-29); crs(u, -d) is shared by two determinants.
+// Division-free rejection filter. With D = |den| in [2^-60, 2^60] and sign-adjusted numerators n' = n * sign(den)
+// (so the exact quotients are X = nx'/D, Y = ny'/D, Z = nz'/D) a triangle CERTAINLY fails the reference's test
+//     xs.x >= 0 && xs.y >= 0 && xs.x + xs.y <= 1 && xs.z >= min_dst          (bvh.h:59-60, xs = RN(n/den))
+// when  nx' < -2^-60  or  ny' < -2^-60           (X or Y < -2^-120: the rounded quotient is negative, not -0)
+//   or  nx' + ny' > D * (1 + 2^-20)               (X + Y > 1 + 2^-20: beyond the three roundings, ~3 * 2^-24)
+//   or  nz' < D * min_dst * (1 - 2^-20)           (Z < min_dst beyond the rounding of RN(Z))
+// Anything else ("maybe") takes the reference's three IEEE divisions and its exact comparisons, so the filter only
+// removes work, never changes an outcome. NaN/inf operands make every comparison false -> "maybe".
+DEV bool tri_hit(V3 ta, V3 av, V3 au, V3 o, V3 d, float min_dst, V3 &xs_out) {
+    V3 at = -d;
+    V3 y = o - ta;
+    V3 c_ut = crs(au, at);
+    float den = dot(av, c_ut);
+    float nx = dot(y, c_ut), ny = dot(av, crs(y, at)), nz = dot(av, crs(au, y));
+    const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+    const float D = __builtin_fabsf(den);
+    const float nxs = __uint_as_float(__float_as_uint(nx) ^ sgn), nys = __uint_as_float(__float_as_uint(ny) ^ sgn),
+                nzs = __uint_as_float(__float_as_uint(nz) ^ sgn);
+    const bool d_ok = (D >= 8.673617379884035e-19f) & (D <= 1.152921504606847e18f); // 2^-60 .. 2^60
+    const bool miss = (nxs < -8.673617379884035e-19f) | (nys < -8.673617379884035e-19f) | (nxs + nys > D * 1.00000095367431640625f) |
+                      (nzs < D * (min_dst * 0.99999904632568359375f));
+    if (d_ok & miss)
+        return false;
+    V3 xs = V3{nx, ny, nz} / den;
+    if (xs.x >= 0 && xs.y >= 0 && xs.x + xs.y <= 1 && xs.z >= min_dst) {
+        xs_out = xs;
+        return true;
+    }
+    return false;
+}
+
+DEV DevTri load_tri(const DevTri *tris, uint32_t idx) {
+    DevTri t;
+    const float4 *p = reinterpret_cast<const float4 *>(tris + idx);
+    float4 *q = reinterpret_cast<float4 *>(&t);
+    q[0] = p[0];
+    q[1] = p[1];
+    q[2] = p[2];
+    return t;
+}
+
+struct Hit {
+    uint32_t k; // DevTri index (BVH order) or RT_NONE
+    float b, c, t;
+};
+
+// ---------------------------------------------------------------------------------------------- traversal stack
+// Deferred far siblings: {child ref, far entry distance, enclosing subtree's local best}. The first LDS_DEPTH
+// positions live in LDS, one column per thread (bank = thread % 32: conflict free whatever the lanes' depths);
+// deeper positions fall back to per-lane scratch. sp counts only ancestors whose BOTH children were hit, so the LDS
+// part serves almost every access (DESIGN.md "traversal stack").
+#ifndef RT_LDS_DEPTH
+#define RT_LDS_DEPTH 12
+#endif
+constexpr int LDS_DEPTH = RT_LDS_DEPTH;
+struct StackMem {
+    uint32_t *lds; // [3][LDS_DEPTH][256] dwords, this thread's column starts at lds + threadIdx.x
+    uint32_t ov_ref[RT_MAX_STACK - LDS_DEPTH];
+    float ov_d[RT_MAX_STACK - LDS_DEPTH];
+    float ov_loc[RT_MAX_STACK - LDS_DEPTH];
+    DEV void push(int sp, uint32_t ref, float d, float loc) {
+        if (sp < LDS_DEPTH) {
+            lds[(0 * LDS_DEPTH + sp) * 256] = ref;
+            lds[(1 * LDS_DEPTH + sp) * 256] = __float_as_uint(d);
+            lds[(2 * LDS_DEPTH + sp) * 256] = __float_as_uint(loc);
+        } else {
+            ov_ref[sp - LDS_DEPTH] = ref;
+            ov_d[sp - LDS_DEPTH] = d;
+            ov_loc[sp - LDS_DEPTH] = loc;
+        }
+    }
+    DEV void pop(int sp, uint32_t &ref, float &d, float &loc) {
+        if (sp < LDS_DEPTH) {
+            ref = lds[(0 * LDS_DEPTH + sp) * 256];
+            d = __uint_as_float(lds[(1 * LDS_DEPTH + sp) * 256]);
+            loc = __uint_as_float(lds[(2 * LDS_DEPTH + sp) * 256]);
+        } else {
+            ref = ov_ref[sp - LDS_DEPTH];
+            d = ov_d[sp - LDS_DEPTH];
+            loc = ov_loc[sp - LDS_DEPTH];
+        }
+    }
+    // light-pdf traversal only needs child refs (bvh.h:237-260 has no ordering / pruning)
+    DEV void push_ref(int sp, uint32_t ref) {
+        if (sp < LDS_DEPTH)
+            lds[(0 * LDS_DEPTH + sp) * 256] = ref;
+        else
+            ov_ref[sp - LDS_DEPTH] = ref;
+    }
+    DEV uint32_t pop_ref(int sp) { return sp < LDS_DEPTH ? lds[(0 * LDS_DEPTH + sp) * 256] : ov_ref[sp - LDS_DEPTH]; }
+};
+#define STACK_LDS_DWORDS (3 * LDS_DEPTH * 256)
+
+// ---------------------------------------------------------------------------------------------- closest hit
+// BVH::intersect_ray (bvh.h:170-180, 195-235) as a resumable per-lane state machine: one call of trav_step visits
+// ONE record — an inner node (both child boxes, 64 B) or one leaf triangle (48 B) — so every lane of the wavefront
+// issues exactly one gather per step whatever it is doing, and a lane can be parked between steps while others shade.
+//   frame = {far child ref, far entry distance d_far, local best of the ENCLOSING subtree at push time}
+//   t_loc = local best t of the subtree being traversed (NaN = no hit yet; fminf ignores NaN operands).
+// On pop the far sibling is visited iff the near subtree found nothing or found t > d_far (bvh.h:221): the
+// reference prunes against the near subtree's local best only. The global best uses the strict "replace iff existing
+// t > new t" rule (bvh.h:132) in DFS order, which equals the nested update_intersection calls.
+constexpr uint32_t T_DONE = 0xFFFFFFFEu, T_POP = 0xFFFFFFFDu;
+struct Trav {
+    V3 o, d, r; // r = 1/d (IEEE) for div_exact_fast
+    uint32_t cur;
+    int sp;
+    float t_loc;
+    Hit best;
+    bool fast; // div_exact_fast is valid for this ray (see its comment)
+    // newest frame (stack position sp-1) cached in registers: a pop followed by a node visit never waits for LDS
+    uint32_t top_ref;
+    float top_d, top_loc;
+};
+DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
+    T.o = o;
+    T.d = d;
+    T.r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float lo = fminf(fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    float hi = fmaxf(fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    T.fast = (bvh.fast_ok != 0u) & (d.x == d.x) & (d.y == d.y) & (d.z == d.z) & (lo >= RANGE_LO) & (hi <= RANGE_HI) & coord_in_fast_range(o.x) &
+             coord_in_fast_range(o.y) & coord_in_fast_range(o.z);
+    T.cur = (bvh.root == RT_NONE || bvh.n_tris == 0) ? T_DONE : bvh.root;
+    T.sp = 0;
+    T.t_loc = RT_NAN;
+    T.best = Hit{RT_NONE, 0.f, 0.f, 0.f};
+}
+
+template <bool STATS> DEV void trav_step(Trav &T, const DevBvh &bvh, StackMem &stk, float min_dst, LaneStats<STATS> &st) {
+    const bool leaf = (T.cur & RT_LEAF_FLAG) != 0;
+    const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (T.cur & ~RT_LEAF_FLAG)) : reinterpret_cast<const float4 *>(bvh.nodes + T.cur);
+    const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+    if (!leaf) {
+        const float4 r3 = p[3];
+        st.node();
+        st.box(2);
+        // DevNode: lmin.xyz lmax.xyz rmin.xyz rmax.xyz left right
+        const V3 lmin = mk(r0.x, r0.y, r0.z), lmax = mk(r0.w, r1.x, r1.y), rmn = mk(r1.z, r1.w, r2.x), rmx = mk(r2.y, r2.z, r2.w);
+        const uint32_t left = __float_as_uint(r3.x), right = __float_as_uint(r3.y);
+        float dl, dr;
+        bool hl, hr;
+        DIAG(2, 1);
+        DIAG_LANES(3);
+        if (T.fast) {
+            hl = box_hit_fast(lmin, lmax, T.o, T.d, T.r, min_dst, dl);
+            hr = box_hit_fast(rmn, rmx, T.o, T.d, T.r, min_dst, dr);
+        } else { // rare ray: a direction/origin component is 0-adjacent, huge or NaN -> reference arithmetic
+            DIAG(6, 1);
+            hl = box_hit_exact(lmin, lmax, T.o, T.d, min_dst, dl);
+            hr = box_hit_exact(rmn, rmx, T.o, T.d, min_dst, dr);
+        }
+        if (hl & hr) {
+            uint32_t near = left, far = right;
+            float dfar = dr;
+            if (dl > dr) { // bvh.h:216 (ties keep left first)
+                near = right;
+                far = left;
+                dfar = dl;
+            }
+            if (T.sp > 0)
+                stk.push(T.sp - 1, T.top_ref, T.top_d, T.top_loc); // spill the previous top
+            T.top_ref = far;
+            T.top_d = dfar;
+            T.top_loc = T.t_loc;
+            ++T.sp;
+            T.t_loc = RT_NAN;
+            T.cur = near;
+        } else if (hl) {
+            T.cur = left;
+        } else if (hr) {
+            T.cur = right;
+        } else {
+            T.cur = T_POP;
+        }
+    } else {
+        DIAG(4, 1);
+        DIAG_LANES(5);
+        // DevTri: a.xyz v.xyz u.xyz prim flags pad
+        const uint32_t flags = __float_as_uint(r2.z);
+        if (flags & 2u)
+            st.node(); // first triangle of its leaf: one BVH::intersect_ray invocation on the leaf node
+        st.tri();
+        V3 xs;
+        if (tri_hit(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), T.o, T.d, min_dst, xs)) {
+            if (T.best.k == RT_NONE || T.best.t > xs.z) {
+                T.best.k = T.cur & ~RT_LEAF_FLAG;
+                T.best.b = xs.x;
+                T.best.c = xs.y;
+                T.best.t = xs.z;
+            }
+            T.t_loc = fminf(T.t_loc, xs.z);
+        }
+        T.cur = (flags & 1u) ? T_POP : T.cur + 1;
+    }
+    while (T.cur == T_POP) {
+        DIAG(7, 1);
+        DIAG_LANES(8);
+        if (T.sp == 0) {
+            T.cur = T_DONE;
+            break;
+        }
+        --T.sp;
+        const uint32_t ref = T.top_ref;
+        const float dfar = T.top_d, saved = T.top_loc;
+        if (T.sp > 0)
+            stk.pop(T.sp - 1, T.top_ref, T.top_d, T.top_loc); // refill the register copy; consumed at the next pop
+        const float t_near = T.t_loc;
+        T.t_loc = fminf(saved, t_near);
+        if (!(t_near <= dfar)) // !has || t_near > d_far (bvh.h:221)
+            T.cur = ref;
+    }
+}
+
+// bvh_mix_dist::pdf (raytracer.h:363-375) = BVH::foreach_intersection (bvh.h:237-260) over the light BVH summing
+// triangle_dist::pdf_at (raytracer.h:255-261) in DFS order (node objects, left subtree, right subtree).
+template <bool STATS> DEV float lights_pdf(const DevScene &S, V3 x, V3 d, StackMem &stk, LaneStats<STATS> &st) {
+    const DevBvh &bvh = S.lights;
+    st.lq();
+    float res = 0;
+    if (bvh.root != RT_NONE && bvh.n_tris != 0) {
+        uint32_t cur = bvh.root;
+        int sp = 0;
+        while (cur != T_DONE) {
+            const bool leaf = (cur & RT_LEAF_FLAG) != 0;
+            const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (cur & ~RT_LEAF_FLAG)) : reinterpret_cast<const float4 *>(bvh.nodes + cur);
+            const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+            if (!leaf) {
+                const float4 r3 = p[3];
+                st.lnode();
+                st.lbox(2);
+                const uint32_t left = __float_as_uint(r3.x), right = __float_as_uint(r3.y);
+                float dl, dr;
+                bool hl = box_hit_exact(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), x, d, EPS, dl);
+                bool hr = box_hit_exact(mk(r1.z, r1.w, r2.x), mk(r2.y, r2.z, r2.w), x, d, EPS, dr);
+                if (hl & hr) {
+                    stk.push_ref(sp++, right);
+                    cur = left;
+                } else if (hl) {
+                    cur = left;
+                } else if (hr) {
+                    cur = right;
+                } else {
+                    cur = T_POP;
+                }
+            } else {
+                const uint32_t k = cur & ~RT_LEAF_FLAG;
+                const uint32_t flags = __float_as_uint(r2.z);
+                if (flags & 2u)
+                    st.lnode();
+                st.ltri();
+                V3 xs;
+                if (tri_hit(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), x, d, EPS, xs)) {
+                    st.lhit();
+                    const float4 aux = *reinterpret_cast<const float4 *>(S.light_aux + k);
+                    V3 y = x + d * xs.z;  // ray.at(t)
+                    V3 dir = norm(y - x); // raytracer.h:259
+                    float mult = len2(x - y) / __builtin_fabsf(dot(dir, mk(aux.x, aux.y, aux.z))); // :79-84
+                    res += mult / aux.w;
+                }
+                cur = (flags & 1u) ? T_POP : cur + 1;
+            }
+            if (cur == T_POP)
+                cur = sp ? stk.pop_ref(--sp) : T_DONE;
+        }
+    }
+    return res / (float)bvh.n_tris; // res / bvh->objects.size()
+}
+
+
+// ---------------------------------------------------------------------------------------------- textures
+// wrap_repeat geometry.h:517-519: std::fmod(std::fmod(x, 1) + 1, 1) evaluated in DOUBLE (float, int -> double
+// overload); fmod(x, 1) == x - trunc(x) exactly.
+DEV float wrap_repeat(float x) {
+    double xd = (double)x;
+    double f = xd - __builtin_trunc(xd);
+    double g = f + 1.0;
+    double h = g - __builtin_trunc(g);
+    return (float)h;
+}
+DEV int mod_inc(int x, int mod) { return x == mod - 1 ? 0 : x + 1; }
+
+enum { TEX_DEFAULT_WHITE = 0, TEX_DEFAULT_NORMAL_UP = 1 };
+
+// Texture::sample (geometry.h:545-575). Texels are RGBA8; k/255.0f and powf(k/255.0f, 2.2f) come from the two
+// 256-entry tables staged in LDS (bit-identical to the per-lookup arithmetic of geometry.h:525-527, 593-594).
+template <bool STATS>
+DEV C4 tex_sample(const DevScene &S, int32_t tex, int dflt, float u, float v, bool gamma, const float *s_lin, const float *s_gam, LaneStats<STATS> &st) {
+    if (tex < 0) {
+        if (dflt == TEX_DEFAULT_WHITE)
+            return C4{1, 1, 1, 1}; // WHITE_TEXTURE geometry.h:601
+        return C4{0.5f, 0.5f, 1, 0}; // NORMAL_UP geometry.h:602
+    }
+    const DevTexture T = S.textures[tex];
+    if (T.count == 1) { // 1x1 fast path returns the texel WITHOUT gamma (geometry.h:548-550)
+        uint32_t p = S.texels[T.offset];
+        return C4{s_lin[p & 255u], s_lin[(p >> 8) & 255u], s_lin[(p >> 16) & 255u], s_lin[p >> 24]};
+    }
+    float tx = wrap_repeat(u) * (float)T.width;
+    float ty = wrap_repeat(v) * (float)T.height;
+    int px = (int)tx;
+    int py = (int)ty;
+    float dx = tx - (float)px;
+    float dy = ty - (float)py;
+    const int w = (int)T.width, h = (int)T.height;
+    const int last = (int)T.count - 1;
+    int i00 = px + py * w;
+    int i01 = px + mod_inc(py, h) * w;
+    int i10 = mod_inc(px, w) + py * w;
+    int i11 = mod_inc(px, w) + mod_inc(py, h) * w;
+    // memory-safety clamp only: the reference indexes out of bounds when wrap_repeat rounds up to 1.0f
+    i00 = min(max(i00, 0), last);
+    i01 = min(max(i01, 0), last);
+    i10 = min(max(i10, 0), last);
+    i11 = min(max(i11, 0), last);
+    const uint32_t *pool = S.texels + T.offset;
+    uint32_t q00 = pool[i00], q01 = pool[i01], q10 = pool[i10], q11 = pool[i11];
+    st.texels(4);
+    const float *rgb = gamma ? s_gam : s_lin;
+    auto dec = [&](uint32_t p) { return C4{rgb[p & 255u], rgb[(p >> 8) & 255u], rgb[(p >> 16) & 255u], s_lin[p >> 24]}; };
+    C4 p00 = dec(q00), p01 = dec(q01), p10 = dec(q10), p11 = dec(q11);
+    return (1 - dx) * ((1 - dy) * p00 + dy * p01) + dx * ((1 - dy) * p10 + dy * p11);
+}
+
+// ---------------------------------------------------------------------------------------------- shading record
+struct Surf { // ray_intersection_info bvh.h:18-29
+    V3 normal, shading_normal;
+    C4 color;
+    V3 emission;
+    float metallic, roughness, ior;
+};
+
+// to_intersection_info bvh.h:80-121
+template <bool STATS>
+DEV Surf make_surf(const DevScene &S, const Hit &h, V3 rd, const float *s_lin, const float *s_gam, LaneStats<STATS> &st) {
+    DevAttr at;
+    {
+        const float4 *p = reinterpret_cast<const float4 *>(S.attrs + h.k);
+        float4 *q = reinterpret_cast<float4 *>(&at);
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            q[i] = p[i];
+    }
+    DevMaterial m;
+    {
+        const float4 *p = reinterpret_cast<const float4 *>(S.materials + at.material);
+        float4 *q = reinterpret_cast<float4 *>(&m);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            q[i] = p[i];
+    }
+    const float b = h.b, c = h.c;
+    const float w0 = (1 - b - c); // triangle::interop geometry.h:497-502
+    V3 normal = ld3(at.gn);
+    bool is_inside = dot(normal, rd) > 0;
+    V3 smooth = norm(ld3(at.n) * w0 + ld3(at.n + 3) * b + ld3(at.n + 6) * c);
+    if (dot(normal, smooth) < 0)
+        smooth = -smooth;
+    float tu = at.uv[0] * w0 + at.uv[2] * b + at.uv[4] * c;
+    float tv = at.uv[1] * w0 + at.uv[3] * b + at.uv[5] * c;
+    V3 tangent = norm(ld3(at.tg) * w0 + ld3(at.tg + 3) * b + ld3(at.tg + 6) * c);
+    V3 bitangent = crs(smooth, tangent);
+    C4 nt = tex_sample(S, m.normal_tex, TEX_DEFAULT_NORMAL_UP, tu, tv, false, s_lin, s_gam, st); // sample_normal geometry.h:577-582
+    V3 normal_loc = norm(mk(nt.r, nt.g, nt.b) * 2 - 1);
+    V3 shading = norm(transform3(normal_loc, tangent, bitangent, smooth));
+    C4 mr = tex_sample(S, m.mr_tex, TEX_DEFAULT_WHITE, tu, tv, false, s_lin, s_gam, st); // geometry.h:623-626
+    C4 ct = tex_sample(S, m.color_tex, TEX_DEFAULT_WHITE, tu, tv, true, s_lin, s_gam, st); // :615-617
+    C4 et = tex_sample(S, m.emissive_tex, TEX_DEFAULT_WHITE, tu, tv, true, s_lin, s_gam, st); // :619-621
+    st.shaded();
+    Surf s;
+    s.normal = is_inside ? -normal : normal;
+    s.shading_normal = is_inside ? -shading : shading;
+    s.color = C4{m.color[0], m.color[1], m.color[2], m.color[3]} * ct;
+    s.emission = mk(m.emission[0], m.emission[1], m.emission[2]) * mk(et.r, et.g, et.b);
+    s.metallic = m.metallic * mr.b;
+    s.roughness = m.roughness * mr.g;
+    s.ior = m.ior;
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------- sampling + BRDF
+template <class R> DEV V3 sphere_uniform(R &rng) { // raytracer.h:94-105
+    float z = uniform_real(rng, -1.0f, 1.0f);
+    float co_z = __builtin_sqrtf(rmax(0.0f, 1 - z * z));
+    float phi = uniform_real(rng, 0.0f, 2 * PI_F);
+    float s, c;
+    rt_sincos(phi, &s, &c);
+    return {co_z * c, co_z * s, z};
+}
+DEV V3 halfway(V3 in_dir, V3 out_dir) { return norm(out_dir - in_dir); } // :131-134
+DEV V3 choose_local_x(V3 n) { // :208-219
+    V3 res{1, 1, 1};
+    if (__builtin_fabsf(n.x) > 0.5f)
+        res.x -= dot(res, n) / n.x;
+    else if (__builtin_fabsf(n.y) > 0.5f)
+        res.y -= dot(res, n) / n.y;
+    else
+        res.z -= dot(res, n) / n.z;
+    return norm(res);
+}
+template <class R> DEV V3 vndf_sample(R &rng, float roughness, V3 in_dir, V3 normal) { // :140-173
+    V3 nx = choose_local_x(normal);
+    V3 ny = crs(normal, nx);
+    V3 v = -norm(mk(dot(nx, in_dir), dot(ny, in_dir), dot(normal, in_dir)));
+    V3 vh = norm(mk(roughness, roughness, 1) * v);
+    float lensq = vh.x * vh.x + vh.y * vh.y;
+    V3 T1 = lensq > 0 ? mk(-vh.y, vh.x, 0) / __builtin_sqrtf(lensq) : mk(1, 0, 0);
+    V3 T2 = crs(vh, T1);
+    float r = __builtin_sqrtf(uniform_real(rng, 0, 1));
+    float phi = 2.0f * PI_F * uniform_real(rng, 0, 1);
+    float sn, cs;
+    rt_sincos(phi, &sn, &cs);
+    float t1 = r * cs;
+    float t2 = r * sn;
+    float s = 0.5f * (1.0f + vh.z);
+    t2 = (1.0f - s) * __builtin_sqrtf(1.0f - pow2(t1)) + s * t2;
+    V3 nh = transform3(mk(t1, t2, __builtin_sqrtf(rmax(0.0f, 1.0f - pow2(t1) - pow2(t2)))), T1, T2, vh);
+    V3 ne = norm(mk(roughness * nh.x, roughness * nh.y, rmax(0.0f, nh.z)));
+    V3 res_n = norm(transform3(ne, nx, ny, normal));
+    return in_dir - 2 * res_n * dot(in_dir, res_n); // reflect geometry.h:36-40
+}
+DEV float vndf_pdf(float roughness, V3 in_dir, V3 normal, V3 dir) { // :175-206
+    V3 nx = choose_local_x(normal);
+    V3 ny = crs(normal, nx);
+    V3 v = -mk(dot(nx, in_dir), dot(ny, in_dir), dot(normal, in_dir));
+    V3 nv = halfway(in_dir, dir);
+    V3 n = mk(dot(nx, nv), dot(ny, nv), dot(normal, nv));
+    float vdn = dot(v, n);
+    if (vdn <= 0)
+        return 0;
+    float vx = v.x * roughness, vy = v.y * roughness;
+    float lambda = (-1 + __builtin_sqrtf(1 + (vx * vx + vy * vy) / pow2(v.z))) / 2;
+    float g1 = 1 / (1 + lambda);
+    float dn = 1 / PI_F / roughness / roughness / pow2(len2(n / mk(roughness, roughness, 1)));
+    float dv = g1 * vdn * dn / rmax(EPS, v.z);
+    return dv / 4 / vdn;
+}
+DEV float heaviside(float x) { return x > 0 ? 1.0f : 0.0f; }
+DEV float specular_brdf(float alpha, V3 in_dir, V3 out_dir, V3 normal) { // :273-293
+    V3 h = halfway(in_dir, out_dir);
+    float ndh = dot(normal, h);
+    float d = pow2(alpha) * heaviside(ndh) / PI_F / pow2(pow2(ndh) * (pow2(alpha) - 1) + 1);
+    float ndo = dot(normal, out_dir);
+    float ndi = dot(normal, -in_dir);
+    float div1 = (__builtin_fabsf(ndo) + __builtin_sqrtf(pow2(alpha) + (1 - pow2(alpha)) * pow2(ndo)));
+    float div2 = (__builtin_fabsf(ndi) + __builtin_sqrtf(pow2(alpha) + (1 - pow2(alpha)) * pow2(ndi)));
+    float v = heaviside(dot(h, out_dir)) * heaviside(dot(h, -in_dir)) / div1 / div2;
+    return v * d;
+}
+DEV V3 pbr_brdf(V3 in_dir, V3 out_dir, const Surf &ii) { // :300-343
+    V3 res{0, 0, 0};
+    V3 base = mk(ii.color.r, ii.color.g, ii.color.b);
+    float alpha = pow2(rmax(ii.roughness, MIN_ROUGHNESS));
+    float sp = specular_brdf(alpha, in_dir, out_dir, ii.shading_normal);
+    V3 spec = mk(sp, sp, sp);
+    float VdotH = dot(-in_dir, halfway(in_dir, out_dir));
+    float fw = pow5(1 - __builtin_fabsf(VdotH));
+    if (ii.metallic < 1) {
+        V3 diffuse = base / PI_F;
+        float f0 = pow2((1 - ii.ior) / (1 + ii.ior));
+        float fr = f0 + (1 - f0) * fw;
+        V3 dielectric = diffuse * (1 - fr) + spec * fr;
+        res = res + (1 - ii.metallic) * dielectric;
+    }
+    if (ii.metallic > 0) {
+        V3 metal = spec * (base + (1 - base) * fw);
+        res = res + ii.metallic * metal;
+    }
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------- one shade() level
+// trace_ray's hit / miss branch (raytracer.h:602-604) + shade (raytracer.h:555-591) for ONE cast result, without the
+// recursion: the caller owns depth bookkeeping and the (emission, scale) fold stack.
+//   terminal : the path ends here and contributes `term` to the innermost pending frame
+//   push     : a scattering event happened: push (emission, scl) and continue with the ray (nro, nrd)
+//   neither  : stochastic alpha pass-through (:559-561): continue with (nro, nrd), no frame
+// RNG draw order is the reference's: alpha coin, technique coin, then the sampler's own draws.
+struct ShadeResult {
+    bool terminal, push;
+    V3 term, emission, scl, nro, nrd;
+};
+template <class R, bool STATS>
+DEV ShadeResult shade_hit(const DevScene &S, const Hit &h, V3 ro, V3 rd, R &rng, bool has_lights, StackMem &stk, const float *s_lin,
+                          const float *s_gam, LaneStats<STATS> &st) {
+    ShadeResult out;
+    out.terminal = false;
+    out.push = false;
+    out.term = out.emission = out.scl = out.nro = mk(0, 0, 0);
+    out.nrd = mk(0, 0, 1);
+    if (h.k == RT_NONE) {
+        out.terminal = true;
+        out.term = ld3(S.bg) * mk(1, 1, 1); // Scene::bg_at with the 1x1 white bg (scene.h:83-89)
+        return out;
+    }
+    const Surf ii = make_surf<STATS>(S, h, rd, s_lin, s_gam, st);
+    const V3 pos = ro + rd * h.t;                          // ray.at(t)
+    if (!(uniform_real(rng, 0.0f, 1.0f) <= ii.color.a)) { // !coin(alpha) :559-561
+        out.nro = pos;
+        out.nrd = rd;
+        return out;
+    }
+    const float vr = pow2(rmax(ii.roughness, MIN_ROUGHNESS)); // :563-564
+    V3 dir;
+    if (uniform_real(rng, 0.0f, 1.0f) <= VNDF_FACTOR) { // :565
+        dir = vndf_sample(rng, vr, rd, ii.shading_normal);
+    } else if (!has_lights) { // dir_dist = cosine_dist (:449)
+        dir = norm(ii.normal + sphere_uniform(rng));
+    } else { // mix_dist{cosine, bvh_mix} (:381-393)
+        const uint32_t pick = rng.below(2);
+        if (pick == 0) {
+            dir = norm(ii.normal + sphere_uniform(rng));
+        } else { // bvh_mix_dist::sample :353-361 + triangle_dist::sample :225-239
+            const uint32_t id = rng.below(S.lights.n_tris);
+            const DevTri lt = load_tri(S.lights.tris, id);
+            float u = uniform_real(rng, 0, 1);
+            float v = uniform_real(rng, 0, 1);
+            if (u + v > 1) {
+                u = 1 - u;
+                v = 1 - v;
+            }
+            V3 p = ld3(lt.a) + ld3(lt.v) * v + ld3(lt.u) * u;
+            dir = norm(p - pos);
+        }
+    }
+    if (isnan_f(dir.x) || isnan_f(dir.y) || isnan_f(dir.z)) { // :569-571
+        out.terminal = true;
+        out.term = ii.emission;
+        return out;
+    }
+    const float VNDF_p = vndf_pdf(vr, rd, ii.shading_normal, dir);
+    float MIS_p;
+    const float cos_p = rmax(dot(ii.normal, dir) / PI_F, 0.0f); // cosine_dist::pdf :123-128
+    if (!has_lights) {
+        MIS_p = cos_p;
+    } else { // mix_dist::pdf :395-407
+        float r = 0;
+        r += cos_p;
+        r += lights_pdf<STATS>(S, pos, dir, stk, st);
+        MIS_p = r / 2.0f;
+    }
+    const float p = VNDF_FACTOR * VNDF_p + (1 - VNDF_FACTOR) * MIS_p;
+    if (p < EPS) { // :576-578
+        out.terminal = true;
+        out.term = ii.emission;
+        return out;
+    }
+    const V3 scl = pbr_brdf(rd, dir, ii) / p * rmax(0.0f, dot(dir, ii.shading_normal));
+    if (len2(scl) == 0.0f) { // :584-586
+        out.terminal = true;
+        out.term = ii.emission;
+        return out;
+    }
+    out.push = true;
+    out.emission = ii.emission;
+    out.scl = scl;
+    out.nro = pos;
+    out.nrd = dir;
+    return out;
+}
+
+} // namespace

@@ -97,6 +97,49 @@ struct DevStats { // device-side counters, see rt_stats in include/rt_abi.h
     unsigned long long samples, casts, nodes, box_tests, tri_tests, shaded, lq, lnodes, lbox, ltri, lhits, texels;
 };
 
+// ---- wavefront pipeline (rt_wavefront.hip): path = one (pixel, sample); queues hold live rays between bounces
+struct alignas(16) WfRay { // 32 B: origin, direction, owning path
+    float o[3];
+    float dx;
+    float dy, dz;
+    uint32_t path;
+    uint32_t pad;
+};
+struct alignas(16) WfHit { // 16 B: closest hit of the ray in the same queue slot
+    uint32_t k;            // DevTri index (scene-BVH order) or RT_NONE
+    float b, c, t;
+};
+struct alignas(16) WfPath { // 32 B, indexed by path id: state that survives across bounces
+    uint32_t rng[4];        // xoshiro128++ state
+    uint32_t depth_left;    // remaining trace_ray budget (raytracer.h:596)
+    uint32_t nb;            // pending shade() frames = entries of this path in fold_e / fold_s
+    uint32_t pad[2];
+};
+struct alignas(16) RtF4 {
+    float x, y, z, w;
+};
+enum { WF_CNT_IN = 0, WF_CNT_OUT = 1, WF_CNT_TICKET = 2, WF_CNT_WORDS = 16 };
+
+struct WfLaunch {
+    uint32_t width, height, samples; // image, total SPP
+    uint32_t first_sample, pass_samples; // this pass renders samples [first_sample, first_sample + pass_samples)
+    uint32_t first_pixel, pass_pixels;   // ... of local pixels [first_pixel, first_pixel + pass_pixels) of this shard
+    uint32_t n_paths;                    // pass_pixels * pass_samples
+    uint32_t shard_index, shard_count, shard_block;
+    uint32_t ray_depth;
+    uint64_t seed;
+    float tan_x, tan_y;
+    WfRay *rays_in, *rays_out;
+    WfHit *hits;
+    WfPath *paths;
+    RtF4 *fold_e, *fold_s; // [ray_depth][n_paths]: emission / scale of pending shade() frames (raytracer.h:588-590)
+    RtF4 *sample_out;        // [n_paths]: sanitised radiance of each finished sample
+    RtF4 *accum;             // [pass_pixels]: running per-pixel sum across sample passes (reference order)
+    float *fb;               // width*height*3
+    uint32_t *counters;      // WF_CNT_*
+    DevStats *stats;         // may be null
+};
+
 struct RenderLaunch {
     uint32_t width, height, samples, rng_mode;
     uint64_t seed;

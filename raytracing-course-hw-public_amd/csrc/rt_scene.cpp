@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -63,8 +64,49 @@ struct rt_scene {
     size_t fb_capacity = 0; // floats
     int num_cus = 0;
     int blocks_per_cu = 8; // upper bound on resident 256-thread blocks per CU; surplus blocks find the ticket exhausted
+    // wavefront pipeline workspace (rt_wavefront.hip), sized for wf_paths_cap paths / wf_pixels_cap pixels per pass
+    uint64_t wf_paths_cap = 0, wf_pixels_cap = 0;
+    uint32_t wf_depth_cap = 0;
+    std::vector<void *> wf_owned;
+    WfRay *wf_rays[2] = {nullptr, nullptr};
+    WfHit *wf_hits = nullptr;
+    WfPath *wf_paths = nullptr;
+    RtF4 *wf_fold_e = nullptr, *wf_fold_s = nullptr, *wf_samples = nullptr, *wf_accum = nullptr;
+    uint32_t *wf_counters = nullptr;
+
+    int ensure_wavefront(uint64_t paths, uint64_t pixels, uint32_t depth) {
+        if (paths <= wf_paths_cap && pixels <= wf_pixels_cap && depth <= wf_depth_cap)
+            return RT_OK;
+        for (void *p : wf_owned)
+            (void)hipFree(p);
+        wf_owned.clear();
+        wf_paths_cap = wf_pixels_cap = 0;
+        wf_depth_cap = 0;
+        auto alloc = [&](size_t bytes, void **out) -> int {
+            *out = nullptr;
+            hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+            if (e != hipSuccess)
+                return rt::fail(e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string("wavefront workspace: ") + hipGetErrorString(e));
+            wf_owned.push_back(*out);
+            return RT_OK;
+        };
+        int rc;
+        if ((rc = alloc(paths * sizeof(WfRay), (void **)&wf_rays[0])) != RT_OK || (rc = alloc(paths * sizeof(WfRay), (void **)&wf_rays[1])) != RT_OK ||
+            (rc = alloc(paths * sizeof(WfHit), (void **)&wf_hits)) != RT_OK || (rc = alloc(paths * sizeof(WfPath), (void **)&wf_paths)) != RT_OK ||
+            (rc = alloc(paths * depth * sizeof(RtF4), (void **)&wf_fold_e)) != RT_OK || (rc = alloc(paths * depth * sizeof(RtF4), (void **)&wf_fold_s)) != RT_OK ||
+            (rc = alloc(paths * sizeof(RtF4), (void **)&wf_samples)) != RT_OK || (rc = alloc(pixels * sizeof(RtF4), (void **)&wf_accum)) != RT_OK ||
+            (rc = alloc(WF_CNT_WORDS * sizeof(uint32_t), (void **)&wf_counters)) != RT_OK)
+            return rc;
+        wf_paths_cap = paths;
+        wf_pixels_cap = pixels;
+        wf_depth_cap = depth;
+        return RT_OK;
+    }
+
     ~rt_scene() {
         (void)hipSetDevice(device);
+        for (void *p : wf_owned)
+            (void)hipFree(p);
         for (void *p : owned)
             (void)hipFree(p);
         if (d_fb)
@@ -326,7 +368,53 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
     int blocks = (int)std::min<uint64_t>((items + 255) / 256, (uint64_t)s->num_cus * s->blocks_per_cu);
     if (blocks < 1)
         blocks = 1;
-    if (L.n_items > 0) {
+    const bool wavefront = p->rng_mode == RT_RNG_DEVICE && !(p->flags & RT_FLAG_MEGAKERNEL);
+    if (L.n_items > 0 && wavefront) {
+        // ---- production path: wavefront pipeline over (pixel tile) x (sample range) passes, all stream-ordered
+        uint64_t max_paths = 8ull << 20;
+        if (const char *e = std::getenv("RT_WF_MAX_PATHS"))
+            max_paths = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 0));
+        const uint64_t tile_pixels = std::min<uint64_t>(local_pixels, max_paths);
+        const uint32_t pass_spp = (uint32_t)std::clamp<uint64_t>(max_paths / tile_pixels, 1, p->samples);
+        int rc = s->ensure_wavefront(tile_pixels * pass_spp, tile_pixels, s->dev.ray_depth);
+        if (rc != RT_OK)
+            return rc;
+        WfLaunch W{};
+        W.width = p->width;
+        W.height = p->height;
+        W.samples = p->samples;
+        W.shard_index = L.shard_index;
+        W.shard_count = L.shard_count;
+        W.shard_block = L.shard_block;
+        W.ray_depth = s->dev.ray_depth;
+        W.seed = p->seed;
+        W.tan_x = L.tan_x;
+        W.tan_y = L.tan_y;
+        W.rays_in = s->wf_rays[0];
+        W.rays_out = s->wf_rays[1];
+        W.hits = s->wf_hits;
+        W.paths = s->wf_paths;
+        W.fold_e = s->wf_fold_e;
+        W.fold_s = s->wf_fold_s;
+        W.sample_out = s->wf_samples;
+        W.accum = s->wf_accum;
+        W.fb = d_fb;
+        W.counters = s->wf_counters;
+        W.stats = L.stats;
+        HIP_TRY(hipEventRecord(s->ev0, s->stream));
+        for (uint64_t p0 = 0; p0 < local_pixels; p0 += tile_pixels) {
+            W.first_pixel = (uint32_t)p0;
+            W.pass_pixels = (uint32_t)std::min<uint64_t>(tile_pixels, local_pixels - p0);
+            for (uint32_t s0 = 0; s0 < p->samples; s0 += pass_spp) {
+                W.first_sample = s0;
+                W.pass_samples = std::min<uint32_t>(pass_spp, p->samples - s0);
+                W.n_paths = W.pass_pixels * W.pass_samples;
+                HIP_TRY(rt::launch_wavefront_pass(s->dev, W, counters, s->num_cus, s0 == 0, s0 + W.pass_samples >= p->samples, s->stream));
+            }
+        }
+        HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    } else if (L.n_items > 0) {
+        // ---- persistent megakernel: reference-RNG parity mode, or RT_FLAG_MEGAKERNEL cross-check
         HIP_TRY(hipEventRecord(s->ev0, s->stream));
         HIP_TRY(rt::launch_render(s->dev, L, counters, blocks, s->stream));
         HIP_TRY(hipEventRecord(s->ev1, s->stream));

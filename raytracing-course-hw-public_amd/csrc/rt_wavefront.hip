@@ -1,0 +1,306 @@
+// rt_wavefront.hip — the production render path (RT_RNG_DEVICE): a wavefront pipeline over PATHS.
+//
+// The reference renders pixel by pixel, sample by sample, bounce by bounce inside one recursive call chain
+// (render_pixel -> trace_ray <-> shade, src/raytracer.h:555-627). On a 64-wide machine that nesting leaves most lanes
+// idle: traversal lengths are heavy-tailed and a lane that finishes early waits for the wave's slowest ray before it may
+// shade. Here a path = one (pixel, sample) and the recursion is cut into stages that each run over ALL live paths:
+//
+//   wf_generate : gen_ray (raytracer.h:527-538) for every path of the pass -> ray queue
+//   per bounce (ray_depth times):
+//     wf_extend : closest hit (BVH::intersect_ray, bvh.h:195-235) for every queued ray. Persistent wavefronts; a lane
+//                 whose traversal ends stores its hit and is refilled from the queue (wave ballot + prefix count, one
+//                 ticket atomic per refill), so the wave stays dense whatever the spread of traversal lengths.
+//     wf_shade  : one shade() level (raytracer.h:555-591) per hit: texture fetches, sampling, pdfs (incl. the light-BVH
+//                 traversal), BRDF. Finished paths fold their (emission, scale) frames back-to-front (the Horner order of
+//                 raytracer.h:588-590) and store the sample; surviving paths are COMPACTED into the next ray queue with
+//                 a wave ballot + prefix sum (one atomic per wave).
+//   wf_resolve  : per pixel, the samples of the pass are added in sample order s = 0,1,2,... onto the running sum, so the
+//                 float sum has exactly the reference's order (raytracer.h:621-626) although samples ran in parallel.
+//
+// Every path owns an xoshiro128++ stream seeded from (seed, pixel, sample) and consumes it in the reference's draw
+// order, so the image is independent of queue order, tiling and GPU count, and bit-identical to the persistent
+// megakernel of rt_kernels.hip and to the CPU oracle in device-RNG mode.
+#include "rt_device_lib.h"
+#include "rt_kernels.h"
+
+namespace {
+
+#ifndef RT_EXT_WAVES_PER_SIMD
+#define RT_EXT_WAVES_PER_SIMD 4
+#endif
+#ifndef RT_EXT_REFILL_MIN
+#define RT_EXT_REFILL_MIN 16 /* refill a wave's idle lanes once this many have finished */
+#endif
+
+DEV uint32_t wf_global_pixel(const WfLaunch &L, uint32_t local_pixel) {
+    const uint32_t local_block = local_pixel / L.shard_block;
+    const uint32_t within = local_pixel - local_block * L.shard_block;
+    return (local_block * L.shard_count + L.shard_index) * L.shard_block + within;
+}
+
+// ------------------------------------------------------------------------------------------------ generate
+template <bool STATS> __global__ __launch_bounds__(256) void wf_generate(const DevScene S, const WfLaunch L) {
+    LaneStats<STATS> st;
+    const V3 cam_pos = ld3(S.cam_pos), cam_right = ld3(S.cam_right), cam_up = ld3(S.cam_up), cam_fwd = ld3(S.cam_fwd);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        L.counters[WF_CNT_IN] = L.n_paths; // the first bounce's queue is the identity: slot i holds path i
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < L.n_paths; i += gridDim.x * blockDim.x) {
+        const uint32_t lp = i / L.pass_samples;
+        const uint32_t ds = i - lp * L.pass_samples;
+        const uint32_t pix = wf_global_pixel(L, L.first_pixel + lp);
+        const uint32_t s = L.first_sample + ds;
+        Rng<RT_RNG_DEVICE> rng;
+        rt_xoshiro_seed(&rng.g, L.seed, pix, s);
+        const uint32_t x = pix % L.width, y = pix / L.width;
+        float ox = uniform_real(rng, 0.0f, 1.0f);
+        float oy = uniform_real(rng, 0.0f, 1.0f);
+        float sx = (2 * ((float)(int)x + ox) / (float)L.width - 1) * L.tan_x;
+        float sy = (2 * ((float)(int)y + oy) / (float)L.height - 1) * L.tan_y;
+        V3 rd = norm(sx * cam_right - sy * cam_up + 1.0f * cam_fwd);
+        WfRay r;
+        r.o[0] = cam_pos.x, r.o[1] = cam_pos.y, r.o[2] = cam_pos.z;
+        r.dx = rd.x, r.dy = rd.y, r.dz = rd.z;
+        r.path = i;
+        r.pad = 0;
+        WfPath p;
+        p.rng[0] = rng.g.s[0], p.rng[1] = rng.g.s[1], p.rng[2] = rng.g.s[2], p.rng[3] = rng.g.s[3];
+        p.depth_left = L.ray_depth;
+        p.nb = 0;
+        p.pad[0] = p.pad[1] = 0;
+        float4 *rq = reinterpret_cast<float4 *>(L.rays_in + i);
+        const float4 *rs = reinterpret_cast<const float4 *>(&r);
+        rq[0] = rs[0];
+        rq[1] = rs[1];
+        float4 *pq = reinterpret_cast<float4 *>(L.paths + i);
+        const float4 *ps = reinterpret_cast<const float4 *>(&p);
+        pq[0] = ps[0];
+        pq[1] = ps[1];
+        st.cast(); // ray_depth >= 1: trace_ray casts (raytracer.h:600)
+    }
+    st.flush(L.stats);
+}
+
+// ------------------------------------------------------------------------------------------------ extend
+template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) void wf_extend(const DevScene S, const WfLaunch L) {
+    __shared__ uint32_t s_stack[STACK_LDS_DWORDS];
+    LaneStats<STATS> st;
+    StackMem stk;
+    stk.lds = s_stack + threadIdx.x;
+    const uint32_t n_in = L.counters[WF_CNT_IN];
+    Trav T;
+    T.cur = T_DONE;
+    T.sp = 0;
+    uint32_t slot = RT_NONE;
+    bool exhausted = n_in == 0; // wave-uniform
+    for (;;) {
+        const bool idle = T.cur == T_DONE;
+        const unsigned long long im = __ballot(idle);
+        const int n_idle = __popcll(im);
+        if (!exhausted && (n_idle >= RT_EXT_REFILL_MIN || n_idle == (int)__popcll(__ballot(1)))) {
+            // refill: ballot + prefix count, one ticket atomic for the whole wave
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+            uint32_t base = 0;
+            if (idle && rank == 0)
+                base = atomicAdd(L.counters + WF_CNT_TICKET, (uint32_t)n_idle);
+            base = __builtin_amdgcn_readfirstlane(__shfl(base, __ffsll((long long)im) - 1));
+            exhausted = base + (uint32_t)n_idle >= n_in;
+            if (idle) {
+                const uint32_t j = base + rank;
+                if (j < n_in) {
+                    const float4 *rq = reinterpret_cast<const float4 *>(L.rays_in + j);
+                    const float4 r0 = rq[0], r1 = rq[1];
+                    slot = j;
+                    trav_init(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y));
+                    if (T.cur == T_DONE) // no geometry at all: immediate miss
+                        *reinterpret_cast<float4 *>(L.hits + j) = make_float4(__uint_as_float(RT_NONE), 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        if (__ballot(T.cur != T_DONE) == 0ull) {
+            if (exhausted)
+                break;
+            continue;
+        }
+        if (T.cur != T_DONE) {
+            trav_step<STATS>(T, S.scene, stk, EPS, st);
+            if (T.cur == T_DONE)
+                *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
+        }
+    }
+    st.flush(L.stats);
+}
+
+// ------------------------------------------------------------------------------------------------ shade
+template <bool STATS> __global__ __launch_bounds__(256, 4) void wf_shade(const DevScene S, const WfLaunch L) {
+    __shared__ float s_lin[256];
+    __shared__ float s_gam[256];
+    __shared__ uint32_t s_stack[STACK_LDS_DWORDS];
+    s_lin[threadIdx.x] = S.lut_linear[threadIdx.x];
+    s_gam[threadIdx.x] = S.lut_gamma[threadIdx.x];
+    __syncthreads();
+    LaneStats<STATS> st;
+    StackMem stk;
+    stk.lds = s_stack + threadIdx.x;
+    const bool has_lights = S.lights.n_tris != 0; // raytracer.h:449-453
+    const uint32_t n_in = L.counters[WF_CNT_IN];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // wave-uniform trip count: ballots below must see the whole wave
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n_in; base += stride) {
+        const uint32_t j = base + threadIdx.x;
+        const bool active = j < n_in;
+        bool survive = false;
+        WfRay nr;
+        if (active) {
+            const float4 *rq = reinterpret_cast<const float4 *>(L.rays_in + j);
+            const float4 r0 = rq[0], r1 = rq[1];
+            const float4 hq = *reinterpret_cast<const float4 *>(L.hits + j);
+            const uint32_t path = __float_as_uint(r1.z);
+            const float4 *pq = reinterpret_cast<const float4 *>(L.paths + path);
+            const float4 p0 = pq[0], p1 = pq[1];
+            Rng<RT_RNG_DEVICE> rng;
+            rng.g.s[0] = __float_as_uint(p0.x), rng.g.s[1] = __float_as_uint(p0.y), rng.g.s[2] = __float_as_uint(p0.z), rng.g.s[3] = __float_as_uint(p0.w);
+            uint32_t depth_left = __float_as_uint(p1.x), nb = __float_as_uint(p1.y);
+            Hit h;
+            h.k = __float_as_uint(hq.x), h.b = hq.y, h.c = hq.z, h.t = hq.w;
+            if (h.k != RT_NONE)
+                depth_left -= 1; // shade(..., max_depth - 1)
+            const ShadeResult sr = shade_hit<Rng<RT_RNG_DEVICE>, STATS>(S, h, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), rng, has_lights, stk, s_lin, s_gam, st);
+            bool terminal = sr.terminal;
+            V3 term = sr.term;
+            if (sr.push) { // emission + trace_ray(...) * scl (raytracer.h:588-590), folded when the path ends
+                L.fold_e[(size_t)nb * L.n_paths + path] = RtF4{sr.emission.x, sr.emission.y, sr.emission.z, 0.f};
+                L.fold_s[(size_t)nb * L.n_paths + path] = RtF4{sr.scl.x, sr.scl.y, sr.scl.z, 0.f};
+                ++nb;
+            }
+            if (!terminal && depth_left == 0) { // trace_ray(..., 0) returns (0,0,0) without casting (:596-598)
+                terminal = true;
+                term = mk(0, 0, 0);
+            }
+            if (terminal) {
+                V3 res = term;
+                while (nb > 0) { // unwind the pending shade() frames: emission + inner * scl
+                    --nb;
+                    const RtF4 fs = L.fold_s[(size_t)nb * L.n_paths + path];
+                    const RtF4 fe = L.fold_e[(size_t)nb * L.n_paths + path];
+                    V3 clr = res * mk(fs.x, fs.y, fs.z);
+                    res = mk(fe.x, fe.y, fe.z) + clr;
+                }
+                if (isnan_f(res.x)) // sanitize_nans raytracer.h:607-616
+                    res.x = 0;
+                if (isnan_f(res.y))
+                    res.y = 0;
+                if (isnan_f(res.z))
+                    res.z = 0;
+                L.sample_out[path] = RtF4{res.x, res.y, res.z, 0.f};
+                st.sample();
+            } else {
+                survive = true;
+                st.cast();
+                nr.o[0] = sr.nro.x, nr.o[1] = sr.nro.y, nr.o[2] = sr.nro.z;
+                nr.dx = sr.nrd.x, nr.dy = sr.nrd.y, nr.dz = sr.nrd.z;
+                nr.path = path;
+                nr.pad = 0;
+                WfPath p;
+                p.rng[0] = rng.g.s[0], p.rng[1] = rng.g.s[1], p.rng[2] = rng.g.s[2], p.rng[3] = rng.g.s[3];
+                p.depth_left = depth_left;
+                p.nb = nb;
+                p.pad[0] = p.pad[1] = 0;
+                float4 *pw = reinterpret_cast<float4 *>(L.paths + path);
+                const float4 *ps = reinterpret_cast<const float4 *>(&p);
+                pw[0] = ps[0];
+                pw[1] = ps[1];
+            }
+        }
+        // compact the survivors of this wave into the next queue: ballot + prefix sum, one atomic per wave
+        const unsigned long long m = __ballot(survive);
+        if (m != 0ull) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            uint32_t obase = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if ((int)(threadIdx.x & 63u) == leader)
+                obase = atomicAdd(L.counters + WF_CNT_OUT, (uint32_t)__popcll(m));
+            obase = __shfl(obase, leader);
+            if (survive) {
+                float4 *rw = reinterpret_cast<float4 *>(L.rays_out + obase + rank);
+                const float4 *rs = reinterpret_cast<const float4 *>(&nr);
+                rw[0] = rs[0];
+                rw[1] = rs[1];
+            }
+        }
+    }
+    st.flush(L.stats);
+}
+
+// next bounce: the out queue becomes the in queue (the host swaps the pointers)
+__global__ void wf_advance(uint32_t *counters) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        counters[WF_CNT_IN] = counters[WF_CNT_OUT];
+        counters[WF_CNT_OUT] = 0;
+        counters[WF_CNT_TICKET] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ resolve
+// render_pixel's `res += sanitize_nans(...)` loop (raytracer.h:621-625) for the samples of this pass, in sample order,
+// continuing the running sum of earlier passes; the final pass divides by the sample count (:626).
+__global__ __launch_bounds__(256) void wf_resolve(const WfLaunch L, int first_pass, int last_pass) {
+    for (uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x; lp < L.pass_pixels; lp += gridDim.x * blockDim.x) {
+        V3 acc = mk(0, 0, 0);
+        if (!first_pass) {
+            const RtF4 a = L.accum[lp];
+            acc = mk(a.x, a.y, a.z);
+        }
+        const RtF4 *src = L.sample_out + (size_t)lp * L.pass_samples;
+        for (uint32_t ds = 0; ds < L.pass_samples; ++ds) {
+            const RtF4 v = src[ds];
+            acc = acc + mk(v.x, v.y, v.z);
+        }
+        if (last_pass) {
+            const V3 out = acc / (float)L.samples;
+            float *dst = L.fb + 3ull * wf_global_pixel(L, L.first_pixel + lp);
+            dst[0] = out.x;
+            dst[1] = out.y;
+            dst[2] = out.z;
+        } else {
+            L.accum[lp] = RtF4{acc.x, acc.y, acc.z, 0.f};
+        }
+    }
+}
+
+} // namespace
+
+namespace rt {
+
+// One pass of the pipeline, fully stream-ordered (no host synchronisation): generate, ray_depth x (extend, shade,
+// advance), resolve. `L.rays_in/rays_out` are swapped locally per bounce.
+hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int num_cus, bool first_pass, bool last_pass, hipStream_t stream) {
+    const int gen_blocks = (int)((L.n_paths + 255u) / 256u < (uint32_t)num_cus * 16u ? (L.n_paths + 255u) / 256u : (uint32_t)num_cus * 16u);
+    const dim3 block(256);
+    hipError_t e = hipMemsetAsync(L.counters, 0, sizeof(uint32_t) * WF_CNT_WORDS, stream);
+    if (e != hipSuccess)
+        return e;
+    if (stats)
+        hipLaunchKernelGGL((wf_generate<true>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
+    else
+        hipLaunchKernelGGL((wf_generate<false>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
+    const int ext_blocks = num_cus * 8;
+    const int shade_blocks = num_cus * 8;
+    for (uint32_t b = 0; b < L.ray_depth; ++b) {
+        if (stats) {
+            hipLaunchKernelGGL((wf_extend<true>), dim3(ext_blocks), block, 0, stream, S, L);
+            hipLaunchKernelGGL((wf_shade<true>), dim3(shade_blocks), block, 0, stream, S, L);
+        } else {
+            hipLaunchKernelGGL((wf_extend<false>), dim3(ext_blocks), block, 0, stream, S, L);
+            hipLaunchKernelGGL((wf_shade<false>), dim3(shade_blocks), block, 0, stream, S, L);
+        }
+        hipLaunchKernelGGL(wf_advance, dim3(1), dim3(64), 0, stream, L.counters);
+        WfRay *t = L.rays_in;
+        L.rays_in = L.rays_out;
+        L.rays_out = t;
+    }
+    const int res_blocks = (int)((L.pass_pixels + 255u) / 256u);
+    hipLaunchKernelGGL(wf_resolve, dim3(res_blocks > 0 ? res_blocks : 1), block, 0, stream, L, first_pass ? 1 : 0, last_pass ? 1 : 0);
+    return hipGetLastError();
+}
+
+} // namespace rt

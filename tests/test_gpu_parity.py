@@ -134,6 +134,29 @@ def test_render_reference_rng_matches_oracle(pairs, gpu, name):
     assert np.array_equal(gpu.tonemap(gfb), gpu.tonemap(ofb))
 
 
+def test_wavefront_equals_megakernel_and_is_pass_invariant(pairs, gpu, monkeypatch):
+    """The wavefront pipeline (default for RT_RNG_DEVICE) and the persistent megakernel (RT_FLAG_MEGAKERNEL) are two
+    schedules of the same per-path arithmetic: framebuffers and event counters must be identical, and splitting the
+    render into more passes (sample ranges x pixel tiles, RT_WF_MAX_PATHS) must not change a bit."""
+    dev, orc, _ = pairs["room_textured"]
+    W, H, SPP = 56, 44, 7
+    ofb, _ = orc.run_raytracer(W, H, SPP, seed=21)
+    mfb, mst = dev.run_raytracer(W, H, SPP, seed=21, megakernel=True, counters=True)
+    wfb, wst = dev.run_raytracer(W, H, SPP, seed=21, counters=True)
+    assert np.array_equal(mfb.view(np.uint32), ofb.view(np.uint32))
+    assert np.array_equal(wfb.view(np.uint32), ofb.view(np.uint32))
+    for k in ("samples", "casts", "nodes_visited", "box_tests", "tri_tests", "shaded_hits", "light_queries", "light_tri_tests", "texel_fetches"):
+        assert mst[k] == wst[k], k
+    for max_paths in (5000, 1500, 1024):  # several sample passes; < W*H -> pixel tiles as well
+        monkeypatch.setenv("RT_WF_MAX_PATHS", str(max_paths))
+        fb, _ = dev.run_raytracer(W, H, SPP, seed=21)
+        assert np.array_equal(fb.view(np.uint32), ofb.view(np.uint32)), max_paths
+        sh = np.zeros_like(fb)
+        for r in range(3):
+            dev.run_raytracer(W, H, SPP, seed=21, shard_index=r, shard_count=3, shard_block=256, out=sh)
+        assert np.array_equal(sh.view(np.uint32), ofb.view(np.uint32)), max_paths
+
+
 def test_shard_union_equals_single(pairs, gpu):
     """Image-row tiles sharded over G ranks: the union of the shards is bit-identical to one GPU."""
     dev, _, _ = pairs["room_plain"]
