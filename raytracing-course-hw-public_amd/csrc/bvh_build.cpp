@@ -198,7 +198,8 @@ FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions) {
         const HostNode &nd = bvh.nodes[node];
         if (dev_index[node] != RT_NONE)
             return dev_index[node];
-        return RT_LEAF_FLAG | nd.obj_begin;
+        const uint32_t cnt = nd.obj_end - nd.obj_begin;
+        return RT_LEAF_FLAG | ((cnt >= 1 && cnt <= RT_LEAF_COOP_MAX) ? (cnt << 27) : 0u) | nd.obj_begin;
     };
     f.nodes.resize(n_inner);
     for (size_t i = 0; i < bvh.nodes.size(); ++i) {

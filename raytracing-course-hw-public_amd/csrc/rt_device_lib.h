@@ -262,7 +262,7 @@ struct Hit {
 #define RT_LDS_DEPTH 12
 #endif
 constexpr int LDS_DEPTH = RT_LDS_DEPTH;
-struct StackMem {
+template <int LDS_DEPTH> struct StackMemT {
     uint32_t *lds; // [3][LDS_DEPTH][256] dwords, this thread's column starts at lds + threadIdx.x
     uint32_t ov_ref[RT_MAX_STACK - LDS_DEPTH];
     float ov_d[RT_MAX_STACK - LDS_DEPTH];
@@ -298,7 +298,9 @@ struct StackMem {
     }
     DEV uint32_t pop_ref(int sp) { return sp < LDS_DEPTH ? lds[(0 * LDS_DEPTH + sp) * 256] : ov_ref[sp - LDS_DEPTH]; }
 };
+using StackMem = StackMemT<LDS_DEPTH>;
 #define STACK_LDS_DWORDS (3 * LDS_DEPTH * 256)
+#define STACK_LDS_DWORDS_FOR(depth) (3 * (depth) * 256)
 
 // ---------------------------------------------------------------------------------------------- closest hit
 // BVH::intersect_ray (bvh.h:170-180, 195-235) as a resumable per-lane state machine: one call of trav_step visits
@@ -335,9 +337,32 @@ DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
     T.best = Hit{RT_NONE, 0.f, 0.f, 0.f};
 }
 
-template <bool STATS> DEV void trav_step(Trav &T, const DevBvh &bvh, StackMem &stk, float min_dst, LaneStats<STATS> &st) {
+// Unwind deferred siblings after a leaf or a double miss: the far child of the newest frame is visited iff the near
+// subtree found nothing or found t > d_far (bvh.h:221); either way the near result is merged into the enclosing
+// subtree's local best. Ends in T_DONE when the stack is empty.
+template <class STK> DEV void trav_pop(Trav &T, STK &stk) {
+    while (T.cur == T_POP) {
+        DIAG(7, 1);
+        DIAG_LANES(8);
+        if (T.sp == 0) {
+            T.cur = T_DONE;
+            break;
+        }
+        --T.sp;
+        const uint32_t ref = T.top_ref;
+        const float dfar = T.top_d, saved = T.top_loc;
+        if (T.sp > 0)
+            stk.pop(T.sp - 1, T.top_ref, T.top_d, T.top_loc); // refill the register copy; consumed at the next pop
+        const float t_near = T.t_loc;
+        T.t_loc = fminf(saved, t_near);
+        if (!(t_near <= dfar)) // !has || t_near > d_far (bvh.h:221)
+            T.cur = ref;
+    }
+}
+
+template <bool STATS, class STK> DEV void trav_step(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
     const bool leaf = (T.cur & RT_LEAF_FLAG) != 0;
-    const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (T.cur & ~RT_LEAF_FLAG)) : reinterpret_cast<const float4 *>(bvh.nodes + T.cur);
+    const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (T.cur & RT_LEAF_BEGIN_MASK)) : reinterpret_cast<const float4 *>(bvh.nodes + T.cur);
     const float4 r0 = p[0], r1 = p[1], r2 = p[2];
     if (!leaf) {
         const float4 r3 = p[3];
@@ -392,7 +417,7 @@ template <bool STATS> DEV void trav_step(Trav &T, const DevBvh &bvh, StackMem &s
         V3 xs;
         if (tri_hit(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), T.o, T.d, min_dst, xs)) {
             if (T.best.k == RT_NONE || T.best.t > xs.z) {
-                T.best.k = T.cur & ~RT_LEAF_FLAG;
+                T.best.k = T.cur & RT_LEAF_BEGIN_MASK;
                 T.best.b = xs.x;
                 T.best.c = xs.y;
                 T.best.t = xs.z;
@@ -401,28 +426,12 @@ template <bool STATS> DEV void trav_step(Trav &T, const DevBvh &bvh, StackMem &s
         }
         T.cur = (flags & 1u) ? T_POP : T.cur + 1;
     }
-    while (T.cur == T_POP) {
-        DIAG(7, 1);
-        DIAG_LANES(8);
-        if (T.sp == 0) {
-            T.cur = T_DONE;
-            break;
-        }
-        --T.sp;
-        const uint32_t ref = T.top_ref;
-        const float dfar = T.top_d, saved = T.top_loc;
-        if (T.sp > 0)
-            stk.pop(T.sp - 1, T.top_ref, T.top_d, T.top_loc); // refill the register copy; consumed at the next pop
-        const float t_near = T.t_loc;
-        T.t_loc = fminf(saved, t_near);
-        if (!(t_near <= dfar)) // !has || t_near > d_far (bvh.h:221)
-            T.cur = ref;
-    }
+    trav_pop(T, stk);
 }
 
 // bvh_mix_dist::pdf (raytracer.h:363-375) = BVH::foreach_intersection (bvh.h:237-260) over the light BVH summing
 // triangle_dist::pdf_at (raytracer.h:255-261) in DFS order (node objects, left subtree, right subtree).
-template <bool STATS> DEV float lights_pdf(const DevScene &S, V3 x, V3 d, StackMem &stk, LaneStats<STATS> &st) {
+template <bool STATS, class STK> DEV float lights_pdf(const DevScene &S, V3 x, V3 d, STK &stk, LaneStats<STATS> &st) {
     const DevBvh &bvh = S.lights;
     st.lq();
     float res = 0;
@@ -431,7 +440,7 @@ template <bool STATS> DEV float lights_pdf(const DevScene &S, V3 x, V3 d, StackM
         int sp = 0;
         while (cur != T_DONE) {
             const bool leaf = (cur & RT_LEAF_FLAG) != 0;
-            const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (cur & ~RT_LEAF_FLAG)) : reinterpret_cast<const float4 *>(bvh.nodes + cur);
+            const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (cur & RT_LEAF_BEGIN_MASK)) : reinterpret_cast<const float4 *>(bvh.nodes + cur);
             const float4 r0 = p[0], r1 = p[1], r2 = p[2];
             if (!leaf) {
                 const float4 r3 = p[3];
@@ -452,7 +461,7 @@ template <bool STATS> DEV float lights_pdf(const DevScene &S, V3 x, V3 d, StackM
                     cur = T_POP;
                 }
             } else {
-                const uint32_t k = cur & ~RT_LEAF_FLAG;
+                const uint32_t k = cur & RT_LEAF_BEGIN_MASK;
                 const uint32_t flags = __float_as_uint(r2.z);
                 if (flags & 2u)
                     st.lnode();
@@ -688,8 +697,8 @@ struct ShadeResult {
     bool terminal, push;
     V3 term, emission, scl, nro, nrd;
 };
-template <class R, bool STATS>
-DEV ShadeResult shade_hit(const DevScene &S, const Hit &h, V3 ro, V3 rd, R &rng, bool has_lights, StackMem &stk, const float *s_lin,
+template <class R, bool STATS, class STK>
+DEV ShadeResult shade_hit(const DevScene &S, const Hit &h, V3 ro, V3 rd, R &rng, bool has_lights, STK &stk, const float *s_lin,
                           const float *s_gam, LaneStats<STATS> &st) {
     ShadeResult out;
     out.terminal = false;

@@ -15,6 +15,11 @@
 
 #define RT_NONE 0xFFFFFFFFu
 #define RT_LEAF_FLAG 0x80000000u
+/* leaf ref = RT_LEAF_FLAG | cnt << 27 | first DevTri index (27 bits). cnt = number of triangles if 1..8, 0 = "walk the
+   leaf with the per-triangle first/last flags" (larger leaves). */
+#define RT_LEAF_BEGIN_MASK 0x07FFFFFFu
+#define RT_LEAF_CNT(ref) (((ref) >> 27) & 15u)
+#define RT_LEAF_COOP_MAX 8u
 #define RT_MAX_STACK 64      /* bvh.h:371 max_depth = 64 -> at most 64 deferred siblings */
 #define RT_MAX_RAY_DEPTH 32u /* reference uses 8 (config.h:17) */
 #define RT_SPAN 256u         /* config.h:13 */
@@ -137,6 +142,7 @@ struct WfLaunch {
     RtF4 *accum;             // [pass_pixels]: running per-pixel sum across sample passes (reference order)
     float *fb;               // width*height*3
     uint32_t *counters;      // WF_CNT_*
+    void *diag;              // development census (-DRT_DIAG), 32 x u64, else unused
     DevStats *stats;         // may be null
 };
 

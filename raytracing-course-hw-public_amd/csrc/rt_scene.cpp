@@ -95,8 +95,9 @@ struct rt_scene {
             (rc = alloc(paths * sizeof(WfHit), (void **)&wf_hits)) != RT_OK || (rc = alloc(paths * sizeof(WfPath), (void **)&wf_paths)) != RT_OK ||
             (rc = alloc(paths * depth * sizeof(RtF4), (void **)&wf_fold_e)) != RT_OK || (rc = alloc(paths * depth * sizeof(RtF4), (void **)&wf_fold_s)) != RT_OK ||
             (rc = alloc(paths * sizeof(RtF4), (void **)&wf_samples)) != RT_OK || (rc = alloc(pixels * sizeof(RtF4), (void **)&wf_accum)) != RT_OK ||
-            (rc = alloc(WF_CNT_WORDS * sizeof(uint32_t), (void **)&wf_counters)) != RT_OK)
+            (rc = alloc(WF_CNT_WORDS * sizeof(uint32_t) + 1024, (void **)&wf_counters)) != RT_OK)
             return rc;
+        (void)hipMemset(wf_counters, 0, WF_CNT_WORDS * sizeof(uint32_t) + 1024);
         wf_paths_cap = paths;
         wf_pixels_cap = pixels;
         wf_depth_cap = depth;
@@ -278,8 +279,8 @@ extern "C" int rt_create(const rt_scene_desc *desc, int device, rt_scene **out) 
         return rt::fail(RT_ERR_INVALID_ARG, "rt_create: ray_depth above RT_MAX_RAY_DEPTH (32)");
     if (desc->n_triangles && (!desc->positions || !desc->normals || !desc->texcoords || !desc->tangents || !desc->material_ids || !desc->materials))
         return rt::fail(RT_ERR_INVALID_ARG, "rt_create: null geometry array");
-    if (desc->n_triangles >= 0x7FFFFFF0u)
-        return rt::fail(RT_ERR_INVALID_ARG, "rt_create: too many triangles");
+    if (desc->n_triangles > RT_LEAF_BEGIN_MASK)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_create: too many triangles (limit 2^27 - 1)");
     rt_scene *s = new rt_scene();
     int rc = create_impl(desc, device, s);
     if (rc != RT_OK) {
@@ -400,6 +401,7 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
         W.accum = s->wf_accum;
         W.fb = d_fb;
         W.counters = s->wf_counters;
+        W.diag = s->wf_counters + 64; // dev census words live behind the queue counters
         W.stats = L.stats;
         HIP_TRY(hipEventRecord(s->ev0, s->stream));
         for (uint64_t p0 = 0; p0 < local_pixels; p0 += tile_pixels) {
@@ -533,5 +535,15 @@ extern "C" int rt_bvh_info(rt_scene *s, int which, uint32_t *n_nodes, uint32_t *
     }
     if (order_out && !b.order.empty())
         std::memcpy(order_out, b.order.data(), b.order.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
+// Development aid (not part of include/rt_abi.h): copies and clears the -DRT_DIAG census words of the wavefront kernels.
+extern "C" int rt_debug_census(rt_scene *s, unsigned long long *out32) {
+    if (!s || !out32 || !s->wf_counters)
+        return RT_ERR_INVALID_ARG;
+    if (hipMemcpy(out32, s->wf_counters + 64, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+        return RT_ERR_HIP;
+    (void)hipMemset(s->wf_counters + 64, 0, 32 * sizeof(unsigned long long));
     return RT_OK;
 }
