@@ -153,6 +153,10 @@ typedef struct rt_stats {
     uint64_t texel_fetches;  /* texels read by Texture::sample (geometry.h:559-568), 4 per non-1x1 lookup */
     double kernel_ms;        /* device time of the render kernel(s), HIP events on the launch stream */
     double total_ms;         /* wall time of rt_render */
+    double dominant_ms;      /* summed device time of the dominant kernel's launches (wf_extend; the megakernel when
+                                that path is used), one HIP event pair per launch */
+    uint32_t dominant_launches;
+    uint32_t reserved;
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* opaque: device-resident scene + both BVHs */

@@ -111,6 +111,9 @@ class RtStats(C.Structure):
         ("texel_fetches", C.c_uint64),
         ("kernel_ms", C.c_double),
         ("total_ms", C.c_double),
+        ("dominant_ms", C.c_double),
+        ("dominant_launches", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:

@@ -370,6 +370,7 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
     if (blocks < 1)
         blocks = 1;
     const bool wavefront = p->rng_mode == RT_RNG_DEVICE && !(p->flags & RT_FLAG_MEGAKERNEL);
+    std::vector<hipEvent_t> extend_events; // (start, stop) per wf_extend launch
     if (L.n_items > 0 && wavefront) {
         // ---- production path: wavefront pipeline over (pixel tile) x (sample range) passes, all stream-ordered
         uint64_t max_paths = 8ull << 20;
@@ -411,7 +412,8 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
                 W.first_sample = s0;
                 W.pass_samples = std::min<uint32_t>(pass_spp, p->samples - s0);
                 W.n_paths = W.pass_pixels * W.pass_samples;
-                HIP_TRY(rt::launch_wavefront_pass(s->dev, W, counters, s->num_cus, s0 == 0, s0 + W.pass_samples >= p->samples, s->stream));
+                HIP_TRY(rt::launch_wavefront_pass(s->dev, W, counters, s->num_cus, s0 == 0, s0 + W.pass_samples >= p->samples, s->stream,
+                                                  stats ? &extend_events : nullptr));
             }
         }
         HIP_TRY(hipEventRecord(s->ev1, s->stream));
@@ -436,6 +438,13 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
             }
         }
     }
+    struct EventCleanup {
+        std::vector<hipEvent_t> &v;
+        ~EventCleanup() {
+            for (hipEvent_t e : v)
+                (void)hipEventDestroy(e);
+        }
+    } event_cleanup{extend_events};
     if (stats) {
         DevStats h{};
         if (counters)
@@ -453,6 +462,13 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
         stats->light_hits = h.lhits;
         stats->texel_fetches = h.texels;
         stats->kernel_ms = ms;
+        stats->dominant_launches = wavefront ? (uint32_t)(extend_events.size() / 2) : (L.n_items > 0 ? 1u : 0u);
+        stats->dominant_ms = wavefront ? 0.0 : ms;
+        for (size_t i = 0; i + 1 < extend_events.size(); i += 2) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, extend_events[i], extend_events[i + 1]) == hipSuccess)
+                stats->dominant_ms += t;
+        }
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     }
     return RT_OK;

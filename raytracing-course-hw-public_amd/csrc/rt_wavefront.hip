@@ -20,6 +20,8 @@
 // Every path owns an xoshiro128++ stream seeded from (seed, pixel, sample) and consumes it in the reference's draw
 // order, so the image is independent of queue order, tiling and GPU count, and bit-identical to the persistent
 // megakernel of rt_kernels.hip and to the CPU oracle in device-RNG mode.
+#include <vector>
+
 #include "rt_device_lib.h"
 #include "rt_kernels.h"
 
@@ -378,7 +380,8 @@ namespace rt {
 
 // One pass of the pipeline, fully stream-ordered (no host synchronisation): generate, ray_depth x (extend, shade,
 // advance), resolve. `L.rays_in/rays_out` are swapped locally per bounce.
-hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int num_cus, bool first_pass, bool last_pass, hipStream_t stream) {
+hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int num_cus, bool first_pass, bool last_pass, hipStream_t stream,
+                                 std::vector<hipEvent_t> *extend_events) {
     const int gen_blocks = (int)((L.n_paths + 255u) / 256u < (uint32_t)num_cus * 16u ? (L.n_paths + 255u) / 256u : (uint32_t)num_cus * 16u);
     const dim3 block(256);
     hipError_t e = hipMemsetAsync(L.counters, 0, sizeof(uint32_t) * WF_CNT_WORDS, stream);
@@ -391,13 +394,26 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
     const int ext_blocks = num_cus * 8;
     const int shade_blocks = num_cus * 8;
     for (uint32_t b = 0; b < L.ray_depth; ++b) {
-        if (stats) {
-            hipLaunchKernelGGL((wf_extend<true>), dim3(ext_blocks), block, 0, stream, S, L);
-            hipLaunchKernelGGL((wf_shade<true>), dim3(shade_blocks), block, 0, stream, S, L);
-        } else {
-            hipLaunchKernelGGL((wf_extend<false>), dim3(ext_blocks), block, 0, stream, S, L);
-            hipLaunchKernelGGL((wf_shade<false>), dim3(shade_blocks), block, 0, stream, S, L);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (extend_events) { // time the dominant kernel per launch (bench.py roofline), HIP events on the launch stream
+            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                extend_events->push_back(e0);
+                extend_events->push_back(e1);
+                (void)hipEventRecord(e0, stream);
+            } else {
+                e0 = e1 = nullptr;
+            }
         }
+        if (stats)
+            hipLaunchKernelGGL((wf_extend<true>), dim3(ext_blocks), block, 0, stream, S, L);
+        else
+            hipLaunchKernelGGL((wf_extend<false>), dim3(ext_blocks), block, 0, stream, S, L);
+        if (e1)
+            (void)hipEventRecord(e1, stream);
+        if (stats)
+            hipLaunchKernelGGL((wf_shade<true>), dim3(shade_blocks), block, 0, stream, S, L);
+        else
+            hipLaunchKernelGGL((wf_shade<false>), dim3(shade_blocks), block, 0, stream, S, L);
         hipLaunchKernelGGL(wf_advance, dim3(1), dim3(64), 0, stream, L.counters);
         WfRay *t = L.rays_in;
         L.rays_in = L.rays_out;
