@@ -78,6 +78,7 @@ def main() -> None:
     ap.add_argument("--triangles", type=int, default=N_TRIANGLES)
     ap.add_argument("--tex-size", type=int, default=TEX_SIZE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 flow on fewer GPUs (all ranks on GPU 0, gather staged through host)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     args = ap.parse_args()
 
@@ -94,7 +95,12 @@ def main() -> None:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if args.backend == "gloo":
+        local_rank = 0  # rehearsal: every rank renders on GPU 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -115,12 +121,14 @@ def main() -> None:
     block = SHARD_ROWS * W
     sharding = importlib.import_module("raytracing-course-hw-public_amd.sharding")
     fb = torch.zeros(n_pix * 3, dtype=torch.float32, device=device)
-    gather = sharding.FramebufferGather(n_pix, block, rank, world, device)
+    gather_device = device if args.backend == "nccl" else torch.device("cpu")
+    gather = sharding.FramebufferGather(n_pix, block, rank, world, gather_device)
     my_pixels = sharding.shard_pixels(n_pix, block, rank, world)
 
     def step():
         _, st = dev.run_raytracer(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr())
-        gather.gather(fb)  # N > 1: RCCL gather of this rank's interleaved blocks to rank 0 (no-op at N = 1)
+        # N > 1: RCCL gather of this rank's interleaved blocks to rank 0 over xGMI (no-op at N = 1)
+        gather.gather(fb if args.backend == "nccl" else fb.cpu())
         return st
 
     def sync():
@@ -141,7 +149,7 @@ def main() -> None:
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
