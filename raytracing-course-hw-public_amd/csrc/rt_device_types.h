@@ -96,6 +96,7 @@ struct DevScene {
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
     float bg[3];
     uint32_t ray_depth;
+    float bounds_lo[3], bounds_inv[3]; // scene AABB: lo and 1/extent, for the ray-ordering key of the wavefront pipeline
 };
 
 struct DevStats { // device-side counters, see rt_stats in include/rt_abi.h
@@ -143,6 +144,11 @@ struct WfLaunch {
     float *fb;               // width*height*3
     uint32_t *counters;      // WF_CNT_*
     void *diag;              // development census (-DRT_DIAG), 32 x u64, else unused
+    const uint32_t *order;   // optional: extend processes queue slots in this order (coherence sort); null = identity
+    uint32_t *sort_keys[2];  // sort workspace: keys / slot indices, double buffered
+    uint32_t *sort_vals[2];
+    void *sort_temp;
+    size_t sort_temp_bytes;
     DevStats *stats;         // may be null
 };
 

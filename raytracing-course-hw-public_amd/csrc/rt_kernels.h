@@ -15,4 +15,6 @@ hipError_t launch_light_pdf(const DevScene &S, const float *rays, uint32_t n, fl
 // `extend_events` (optional): receives one (start, stop) event pair per wf_extend launch, recorded on `stream`
 hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int num_cus, bool first_pass, bool last_pass, hipStream_t stream,
                                  std::vector<hipEvent_t> *extend_events);
+// bytes of temporary storage rocPRIM's radix sort needs for `n` (key, slot) pairs
+size_t wavefront_sort_temp_bytes(size_t n);
 } // namespace rt

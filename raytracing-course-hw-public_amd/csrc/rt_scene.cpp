@@ -73,6 +73,9 @@ struct rt_scene {
     WfPath *wf_paths = nullptr;
     RtF4 *wf_fold_e = nullptr, *wf_fold_s = nullptr, *wf_samples = nullptr, *wf_accum = nullptr;
     uint32_t *wf_counters = nullptr;
+    uint32_t *wf_sort_keys[2] = {nullptr, nullptr}, *wf_sort_vals[2] = {nullptr, nullptr};
+    void *wf_sort_temp = nullptr;
+    size_t wf_sort_temp_bytes = 0;
 
     int ensure_wavefront(uint64_t paths, uint64_t pixels, uint32_t depth) {
         if (paths <= wf_paths_cap && pixels <= wf_pixels_cap && depth <= wf_depth_cap)
@@ -96,6 +99,11 @@ struct rt_scene {
             (rc = alloc(paths * depth * sizeof(RtF4), (void **)&wf_fold_e)) != RT_OK || (rc = alloc(paths * depth * sizeof(RtF4), (void **)&wf_fold_s)) != RT_OK ||
             (rc = alloc(paths * sizeof(RtF4), (void **)&wf_samples)) != RT_OK || (rc = alloc(pixels * sizeof(RtF4), (void **)&wf_accum)) != RT_OK ||
             (rc = alloc(WF_CNT_WORDS * sizeof(uint32_t) + 1024, (void **)&wf_counters)) != RT_OK)
+            return rc;
+        wf_sort_temp_bytes = rt::wavefront_sort_temp_bytes(paths);
+        if ((rc = alloc(paths * 4, (void **)&wf_sort_keys[0])) != RT_OK || (rc = alloc(paths * 4, (void **)&wf_sort_keys[1])) != RT_OK ||
+            (rc = alloc(paths * 4, (void **)&wf_sort_vals[0])) != RT_OK || (rc = alloc(paths * 4, (void **)&wf_sort_vals[1])) != RT_OK ||
+            (rc = alloc(wf_sort_temp_bytes, &wf_sort_temp)) != RT_OK)
             return rc;
         (void)hipMemset(wf_counters, 0, WF_CNT_WORDS * sizeof(uint32_t) + 1024);
         wf_paths_cap = paths;
@@ -258,6 +266,15 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
     std::memcpy(D.cam_fwd, d->camera.forward, 12);
     std::memcpy(D.bg, d->bg_color, 12);
     D.ray_depth = d->ray_depth;
+    for (int k = 0; k < 3; ++k) { // scene bounds for the ray-ordering key (root node box of the scene BVH)
+        float lo = 0.f, hi = 1.f;
+        if (s->host_bvh[0].root != RT_NONE && !s->host_bvh[0].nodes.empty()) {
+            lo = s->host_bvh[0].nodes[s->host_bvh[0].root].lo[k];
+            hi = s->host_bvh[0].nodes[s->host_bvh[0].root].hi[k];
+        }
+        D.bounds_lo[k] = lo;
+        D.bounds_inv[k] = (hi > lo) ? 1.0f / (hi - lo) : 0.0f;
+    }
     s->cam = d->camera;
 
     void *p = nullptr;
@@ -373,7 +390,19 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
     std::vector<hipEvent_t> extend_events; // (start, stop) per wf_extend launch
     if (L.n_items > 0 && wavefront) {
         // ---- production path: wavefront pipeline over (pixel tile) x (sample range) passes, all stream-ordered
-        uint64_t max_paths = 8ull << 20;
+        // Paths per pass: the larger a pass, the smaller the share of each bounce launch's drain phase (measured on
+        // S-sponza 1000x1000x64: 8 M paths 148, 16 M 158, 32 M 164, 64 M 167 Msamples/s). 64 M paths x 384 B = 25.8 GB
+        // of workspace, sized for 288 GB of HBM; capped by free device memory below.
+        uint64_t max_paths = 64ull << 20;
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const uint64_t per_path = 2 * sizeof(WfRay) + sizeof(WfHit) + sizeof(WfPath) + (2ull * s->dev.ray_depth + 1) * sizeof(RtF4);
+                const uint64_t have = free_b + s->wf_paths_cap * per_path; // what is already ours can be reused
+                const uint64_t fit = (uint64_t)(0.6 * (double)have) / per_path;
+                max_paths = std::max<uint64_t>(1u << 16, std::min(max_paths, fit));
+            }
+        }
         if (const char *e = std::getenv("RT_WF_MAX_PATHS"))
             max_paths = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 0));
         const uint64_t tile_pixels = std::min<uint64_t>(local_pixels, max_paths);
@@ -403,6 +432,14 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
         W.fb = d_fb;
         W.counters = s->wf_counters;
         W.diag = s->wf_counters + 64; // dev census words live behind the queue counters
+        const char *sort_env = std::getenv("RT_WF_SORT");
+        const bool sort_rays = sort_env ? std::atoi(sort_env) != 0 : true;
+        for (int k = 0; k < 2; ++k) {
+            W.sort_keys[k] = sort_rays ? s->wf_sort_keys[k] : nullptr;
+            W.sort_vals[k] = sort_rays ? s->wf_sort_vals[k] : nullptr;
+        }
+        W.sort_temp = s->wf_sort_temp;
+        W.sort_temp_bytes = s->wf_sort_temp_bytes;
         W.stats = L.stats;
         HIP_TRY(hipEventRecord(s->ev0, s->stream));
         for (uint64_t p0 = 0; p0 < local_pixels; p0 += tile_pixels) {

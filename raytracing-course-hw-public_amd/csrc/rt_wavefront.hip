@@ -20,7 +20,10 @@
 // Every path owns an xoshiro128++ stream seeded from (seed, pixel, sample) and consumes it in the reference's draw
 // order, so the image is independent of queue order, tiling and GPU count, and bit-identical to the persistent
 // megakernel of rt_kernels.hip and to the CPU oracle in device-RNG mode.
+#include <cstring>
 #include <vector>
+
+#include <rocprim/rocprim.hpp>
 
 #include "rt_device_lib.h"
 #include "rt_kernels.h"
@@ -190,6 +193,9 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
     T.sp = 0;
     uint32_t slot = RT_NONE;
     bool exhausted = n_in == 0; // wave-uniform
+#ifdef RT_STAMP
+    unsigned long long t_loop = __builtin_amdgcn_s_memtime(), c_batch = 0, c_node = 0, c_total = 0, n_batch = 0, n_node = 0;
+#endif
     for (;;) {
         const bool idle = T.cur == T_DONE;
         const unsigned long long im = __ballot(idle);
@@ -203,8 +209,9 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
             base = __builtin_amdgcn_readfirstlane(__shfl(base, __ffsll((long long)im) - 1));
             exhausted = base + (uint32_t)n_idle >= n_in;
             if (idle) {
-                const uint32_t j = base + rank;
-                if (j < n_in) {
+                const uint32_t jq = base + rank;
+                if (jq < n_in) {
+                    const uint32_t j = L.order ? L.order[jq] : jq; // coherence-sorted processing order
                     const float4 *rq = reinterpret_cast<const float4 *>(L.rays_in + j);
                     const float4 r0 = rq[0], r1 = rq[1];
                     slot = j;
@@ -224,6 +231,10 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
                 break;
             continue;
         }
+#ifdef RT_STAMP
+        const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+        const bool did_batch = (sm == 0ull || __popcll(lm) >= RT_EXT_LEAF_MIN);
+#endif
         if (sm == 0ull || __popcll(lm) >= RT_EXT_LEAF_MIN) {
             leaf_batch<STATS>(T, S.scene, stk, at_leaf, s_owner, s_min, s_bc, st);
         } else if (stepper) {
@@ -231,9 +242,34 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
             DIAG_LANES(19);
             trav_step<STATS>(T, S.scene, stk, EPS, st);
         }
+#ifdef RT_STAMP
+        {
+            const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
+            if (did_batch) {
+                c_batch += tq1 - tq0;
+                n_batch += 1;
+            } else {
+                c_node += tq1 - tq0;
+                n_node += 1;
+            }
+            c_total += tq1 - t_loop;
+            t_loop = tq1;
+        }
+#endif
         if (active && T.cur == T_DONE)
             *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
     }
+#ifdef RT_STAMP
+    if ((threadIdx.x & 63u) == 0u) { // development build only: per-wave cycle sums -> census words 20..25
+        unsigned long long *dg = reinterpret_cast<unsigned long long *>(L.diag);
+        atomicAdd(dg + 20, c_batch);
+        atomicAdd(dg + 21, c_node);
+        atomicAdd(dg + 22, c_total);
+        atomicAdd(dg + 23, n_batch);
+        atomicAdd(dg + 24, n_node);
+        atomicAdd(dg + 25, 1ull);
+    }
+#endif
     st.flush(L.stats);
 }
 
@@ -338,6 +374,30 @@ template <bool STATS> __global__ __launch_bounds__(256, 4) void wf_shade(const D
     st.flush(L.stats);
 }
 
+// Ray-ordering key for secondary bounces: Morton code of the origin's cell in a 64^3 grid over the scene bounds (18 bits)
+// followed by the direction octant (3 bits). Rays that start close together and head the same way end up in the same
+// wave of wf_extend, so their gathers touch the same nodes (cache lines, L2 residency). Ordering never changes a result:
+// every path's arithmetic is independent of where it sits in the queue.
+DEV uint32_t spread3(uint32_t v) { // 6 bits -> every third bit
+    v &= 63u;
+    v = (v | (v << 8)) & 0x0300Fu;
+    v = (v | (v << 4)) & 0x030C3u;
+    v = (v | (v << 2)) & 0x09249u;
+    return v;
+}
+__global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLaunch L, uint32_t n) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const float4 *rq = reinterpret_cast<const float4 *>(L.rays_in + j);
+        const float4 r0 = rq[0], r1 = rq[1];
+        const float fx = (r0.x - S.bounds_lo[0]) * S.bounds_inv[0], fy = (r0.y - S.bounds_lo[1]) * S.bounds_inv[1], fz = (r0.z - S.bounds_lo[2]) * S.bounds_inv[2];
+        const uint32_t cx = (uint32_t)fminf(fmaxf(fx * 64.0f, 0.0f), 63.0f), cy = (uint32_t)fminf(fmaxf(fy * 64.0f, 0.0f), 63.0f), cz = (uint32_t)fminf(fmaxf(fz * 64.0f, 0.0f), 63.0f);
+        const uint32_t morton = spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
+        const uint32_t oct = (r0.w < 0.0f ? 1u : 0u) | (r1.x < 0.0f ? 2u : 0u) | (r1.y < 0.0f ? 4u : 0u);
+        L.sort_keys[0][j] = (morton << 3) | oct;
+        L.sort_vals[0][j] = j;
+    }
+}
+
 // next bounce: the out queue becomes the in queue (the host swaps the pointers)
 __global__ void wf_advance(uint32_t *counters) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -393,7 +453,28 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         hipLaunchKernelGGL((wf_generate<false>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
     const int ext_blocks = num_cus * 8;
     const int shade_blocks = num_cus * 8;
+    static uint32_t *h_count = nullptr; // pinned word for the per-bounce queue size read-back
+    if (L.sort_keys[0] && !h_count && hipHostMalloc((void **)&h_count, sizeof(uint32_t)) != hipSuccess)
+        h_count = nullptr;
+    uint32_t n_active = L.n_paths;
     for (uint32_t b = 0; b < L.ray_depth; ++b) {
+        L.order = nullptr;
+        if (b > 0 && L.sort_keys[0] && h_count) { // primary rays are coherent as generated
+            if (hipMemcpyAsync(h_count, L.counters + WF_CNT_IN, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+                return hipGetLastError();
+            n_active = *h_count;
+            if (n_active == 0)
+                break;
+            if (n_active >= 4096u) {
+                const uint32_t kb = (n_active + 255u) / 256u < (uint32_t)num_cus * 16u ? (n_active + 255u) / 256u : (uint32_t)num_cus * 16u;
+                hipLaunchKernelGGL(wf_sort_keys, dim3(kb), block, 0, stream, S, L, n_active);
+                size_t tmp = L.sort_temp_bytes;
+                hipError_t se = rocprim::radix_sort_pairs(L.sort_temp, tmp, L.sort_keys[0], L.sort_keys[1], L.sort_vals[0], L.sort_vals[1], (size_t)n_active, 0u, 21u, stream);
+                if (se != hipSuccess)
+                    return se;
+                L.order = L.sort_vals[1];
+            }
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (extend_events) { // time the dominant kernel per launch (bench.py roofline), HIP events on the launch stream
             if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
@@ -422,6 +503,13 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
     const int res_blocks = (int)((L.pass_pixels + 255u) / 256u);
     hipLaunchKernelGGL(wf_resolve, dim3(res_blocks > 0 ? res_blocks : 1), block, 0, stream, L, first_pass ? 1 : 0, last_pass ? 1 : 0);
     return hipGetLastError();
+}
+
+size_t wavefront_sort_temp_bytes(size_t n) {
+    size_t tmp = 0;
+    uint32_t *k = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, k, k, k, k, n, 0u, 21u, (hipStream_t) nullptr);
+    return tmp;
 }
 
 } // namespace rt

@@ -157,6 +157,53 @@ def test_wavefront_equals_megakernel_and_is_pass_invariant(pairs, gpu, monkeypat
         assert np.array_equal(sh.view(np.uint32), ofb.view(np.uint32)), max_paths
 
 
+def test_full_size_bench_scene_parity(gpu, oracle, sg):
+    """BASELINE config 3 at full size (S-sponza: 262 172 triangles, 16 texture sets, 1000x1000): the whole image at
+    1 SPP against the oracle (bit-exact framebuffer + identical event counters), 60 000 random rays for bit-exact hit
+    records, and the size-independent properties at 8 SPP: wavefront == megakernel, union of 4 shards == single
+    render, ray ordering on/off and pass size do not change a bit."""
+    import os
+
+    sc = sg.room_scene(262144, seed=0x5EED5EED, tex_size=256, n_tex_sets=16, n_materials=64, n_lights=16, light_strength=20.0,
+                       alpha_fraction=0.02, offset=0.15, camera=sg.look_camera((-15.0, 4.0, 0.0), yaw_deg=-90.0, yfov=0.9))
+    dev = gpu.DeviceScene(sc)
+    orc = oracle.OracleScene(sc)
+    W = H = 1000
+    gfb, gst = dev.run_raytracer(W, H, 1, seed=0x5EED5EED, counters=True)
+    ofb, ost = orc.run_raytracer(W, H, 1, seed=0x5EED5EED)
+    assert np.array_equal(gfb.view(np.uint32), ofb.view(np.uint32)), f"{int((gfb != ofb).any(axis=2).sum())} of 10^6 pixels differ"
+    for k in ("samples", "casts", "nodes_visited", "box_tests", "tri_tests", "shaded_hits", "light_queries", "light_tri_tests", "light_hits", "texel_fetches"):
+        assert gst[k] == ost[k], k
+    assert gst["casts"] > 3_000_000 and gst["nodes_visited"] > 300_000_000
+    rays = random_rays(sc, 60000, seed=4242)
+    gp, gb = dev.cast_rays(rays)
+    op, ob = orc.cast_rays(rays)
+    assert np.array_equal(gp, op) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+    orc.close()
+    # size-independent properties at 8 SPP (8 M paths)
+    a, _ = dev.run_raytracer(W, H, 8, seed=7)
+    m, _ = dev.run_raytracer(W, H, 8, seed=7, megakernel=True)
+    assert np.array_equal(a.view(np.uint32), m.view(np.uint32))
+    sh = np.zeros_like(a)
+    for r in range(4):
+        dev.run_raytracer(W, H, 8, seed=7, shard_index=r, shard_count=4, shard_block=8 * W, out=sh)
+    assert np.array_equal(sh.view(np.uint32), a.view(np.uint32))
+    old = {k: os.environ.get(k) for k in ("RT_WF_SORT", "RT_WF_MAX_PATHS")}
+    try:
+        os.environ["RT_WF_SORT"] = "0"
+        os.environ["RT_WF_MAX_PATHS"] = str(3_000_000)
+        b, _ = dev.run_raytracer(W, H, 8, seed=7)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert np.array_equal(b.view(np.uint32), a.view(np.uint32))
+    assert np.isfinite(a).all() and a.mean() > 1e-4
+    dev.close()
+
+
 def test_shard_union_equals_single(pairs, gpu):
     """Image-row tiles sharded over G ranks: the union of the shards is bit-identical to one GPU."""
     dev, _, _ = pairs["room_plain"]

@@ -3,7 +3,7 @@
 import ctypes as C, importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
-os.environ["RT_AMD_LIB"] = os.path.join(ROOT, "raytracing-course-hw-public_amd/csrc/variants/diag.so")
+os.environ["RT_AMD_LIB"] = os.path.join(ROOT, "raytracing-course-hw-public_amd/csrc/variants/%s.so" % os.environ.get("RT_DIAG_VARIANT", "diag"))
 rt = importlib.import_module("raytracing-course-hw-public_amd")
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 sc = rt.scenegen.room_scene(262144, seed=0x5EED5EED, tex_size=1024, n_tex_sets=16, n_materials=64, n_lights=16, light_strength=20.0,
@@ -15,7 +15,7 @@ lib = rt.lib(); lib.rt_debug_census.argtypes = [C.c_void_p, C.c_void_p]; lib.rt_
 _, st = dev.run_raytracer(1000, 1000, spp, seed=1, counters=True)
 lib.rt_debug_census(dev._h, out.ctypes.data)
 n = 1e6 * spp
-names = {12: "iterations", 13: "batches", 14: "batch_leaf_lanes", 15: "rounds", 16: "pairs", 17: "hit_path_execs", 18: "node_step_execs", 19: "node_step_lanes", 7: "pop_iters", 8: "pop_lanes", 2: "inner_execs", 3: "inner_lanes", 4: "seqtri_execs"}
+names = {12: "iterations", 13: "batches", 14: "batch_leaf_lanes", 15: "rounds", 16: "pairs", 17: "hit_path_execs", 18: "node_step_execs", 19: "node_step_lanes", 7: "pop_iters", 8: "pop_lanes", 2: "inner_execs", 3: "inner_lanes", 4: "seqtri_execs", 20: "cycles_batches", 21: "cycles_node_steps", 22: "cycles_total_iter", 23: "n_batches(stamp)", 24: "n_node_steps(stamp)", 25: "waves"}
 for k, nm in sorted(names.items()):
     print(f"{nm:18s} {float(out[k]):.4g}  per-sample {float(out[k]) / n:.3f}")
 print("kernel_ms", st["kernel_ms"], "leaf lanes/batch", float(out[14]) / max(1, float(out[13])), "rounds/batch", float(out[15]) / max(1, float(out[13])),
