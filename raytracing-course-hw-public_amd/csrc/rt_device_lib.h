@@ -362,6 +362,24 @@ DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
 // Unwind deferred siblings after a leaf or a double miss: the far child of the newest frame is visited iff the near
 // subtree found nothing or found t > d_far (bvh.h:221); either way the near result is merged into the enclosing
 // subtree's local best. Ends in T_DONE when the stack is empty.
+// One frame of trav_pop for a lane in state T_POP: afterwards T.cur is the far child (visit it), T_DONE (stack empty)
+// or still T_POP (sibling pruned: pop again later). Lets a wave unwind without a data-dependent inner loop.
+template <class STK> DEV void trav_pop_once(Trav &T, STK &stk) {
+    if (T.sp == 0) {
+        T.cur = T_DONE;
+        return;
+    }
+    --T.sp;
+    const uint32_t ref = T.top_ref;
+    const float dfar = T.top_d, saved = T.top_loc;
+    if (T.sp > 0)
+        stk.pop(T.sp - 1, T.top_ref, T.top_d, T.top_loc);
+    const float t_near = T.t_loc;
+    T.t_loc = fminf(saved, t_near);
+    if (!(t_near <= dfar)) // !has || t_near > d_far (bvh.h:221)
+        T.cur = ref;
+}
+
 template <class STK> DEV void trav_pop(Trav &T, STK &stk) {
     while (T.cur == T_POP) {
         DIAG(7, 1);
@@ -382,7 +400,9 @@ template <class STK> DEV void trav_pop(Trav &T, STK &stk) {
     }
 }
 
-template <bool STATS, class STK> DEV void trav_step(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
+// One record: an inner node (two child boxes) or one triangle of a big leaf. Leaves T.cur == T_POP when the lane has to
+// unwind; the caller chooses how (trav_pop: loop until resolved; trav_pop_once: one frame now, the rest later).
+template <bool STATS, class STK> DEV void trav_step_core(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
     const bool leaf = (T.cur & RT_LEAF_FLAG) != 0;
     const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (T.cur & RT_LEAF_BEGIN_MASK)) : reinterpret_cast<const float4 *>(bvh.nodes + T.cur);
     const float4 r0 = p[0], r1 = p[1], r2 = p[2];
@@ -448,6 +468,9 @@ template <bool STATS, class STK> DEV void trav_step(Trav &T, const DevBvh &bvh, 
         }
         T.cur = (flags & 1u) ? T_POP : T.cur + 1;
     }
+}
+template <bool STATS, class STK> DEV void trav_step(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
+    trav_step_core<STATS>(T, bvh, stk, min_dst, st);
     trav_pop(T, stk);
 }
 

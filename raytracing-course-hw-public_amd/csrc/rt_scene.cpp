@@ -439,6 +439,7 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
             W.sort_vals[k] = sort_rays ? s->wf_sort_vals[k] : nullptr;
         }
         W.sort_temp = s->wf_sort_temp;
+        W.sort_mode = sort_env ? (uint32_t)std::atoi(sort_env) : 1u;
         W.sort_temp_bytes = s->wf_sort_temp_bytes;
         W.stats = L.stats;
         HIP_TRY(hipEventRecord(s->ev0, s->stream));

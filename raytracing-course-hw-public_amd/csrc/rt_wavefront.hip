@@ -37,6 +37,9 @@ namespace {
 #define RT_EXT_LDS_DEPTH 6 /* LDS part of the traversal stack in wf_extend: 6 -> 26 KB/block -> 6 blocks (24 waves) per CU */
 #endif
 using ExtStack = StackMemT<RT_EXT_LDS_DEPTH>;
+#ifndef RT_EXT_POP_LOOP
+#define RT_EXT_POP_LOOP 1 /* 1: unwind with a loop inside the step (measured faster); 0: one frame per pass */
+#endif
 #ifndef RT_EXT_REFILL_MIN
 #define RT_EXT_REFILL_MIN 16 /* refill a wave's idle lanes once this many have finished */
 #endif
@@ -163,7 +166,11 @@ DEV void leaf_batch(Trav &T, const DevBvh &bvh, ExtStack &stk, bool at_leaf, uin
             T.t_loc = fminf(T.t_loc, t);
         }
         T.cur = T_POP;
+#if RT_EXT_POP_LOOP
         trav_pop(T, stk);
+#else
+        trav_pop_once(T, stk);
+#endif
     }
 }
 
@@ -222,11 +229,25 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
             }
         }
         DIAG(12, 1);
+#if !RT_EXT_POP_LOOP
+        if (T.cur == T_POP) { // unwinding continues one frame per pass: no data-dependent loop inside the wave
+            trav_pop_once(T, stk);
+            if (T.cur == T_DONE)
+                *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
+        }
+        const bool popping = T.cur == T_POP;
+#else
+        constexpr bool popping = false;
+#endif
         const bool active = T.cur != T_DONE;
-        const bool at_leaf = active && (T.cur & RT_LEAF_FLAG) != 0 && RT_LEAF_CNT(T.cur) != 0;
-        const bool stepper = active && !at_leaf; // inner node, or a big leaf walked triangle by triangle
+        const bool at_leaf = active && !popping && (T.cur & RT_LEAF_FLAG) != 0 && RT_LEAF_CNT(T.cur) != 0;
+        const bool stepper = active && !popping && !at_leaf; // inner node, or a big leaf walked triangle by triangle
         const unsigned long long lm = __ballot(at_leaf), sm = __ballot(stepper);
         if ((lm | sm) == 0ull) {
+#if !RT_EXT_POP_LOOP
+            if (__ballot(popping) != 0ull)
+                continue; // only unwinding lanes left: next pass pops again
+#endif
             if (exhausted)
                 break;
             continue;
@@ -240,7 +261,13 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
         } else if (stepper) {
             DIAG(18, 1);
             DIAG_LANES(19);
-            trav_step<STATS>(T, S.scene, stk, EPS, st);
+            trav_step_core<STATS>(T, S.scene, stk, EPS, st);
+#if RT_EXT_POP_LOOP
+            trav_pop(T, stk);
+#else
+            if (T.cur == T_POP)
+                trav_pop_once(T, stk);
+#endif
         }
 #ifdef RT_STAMP
         {
@@ -393,7 +420,16 @@ __global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLa
         const uint32_t cx = (uint32_t)fminf(fmaxf(fx * 64.0f, 0.0f), 63.0f), cy = (uint32_t)fminf(fmaxf(fy * 64.0f, 0.0f), 63.0f), cz = (uint32_t)fminf(fmaxf(fz * 64.0f, 0.0f), 63.0f);
         const uint32_t morton = spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
         const uint32_t oct = (r0.w < 0.0f ? 1u : 0u) | (r1.x < 0.0f ? 2u : 0u) | (r1.y < 0.0f ? 4u : 0u);
-        L.sort_keys[0][j] = (morton << 3) | oct;
+        uint32_t key = (morton << 3) | oct; // mode 1: 64^3 cell, then octant
+        if (L.sort_mode == 2) { // 16^3 cell (12 bits), then a 9-bit direction code (3 bits per component)
+            const uint32_t dxq = (uint32_t)fminf(fmaxf((r0.w * 0.5f + 0.5f) * 8.0f, 0.0f), 7.0f), dyq = (uint32_t)fminf(fmaxf((r1.x * 0.5f + 0.5f) * 8.0f, 0.0f), 7.0f),
+                           dzq = (uint32_t)fminf(fmaxf((r1.y * 0.5f + 0.5f) * 8.0f, 0.0f), 7.0f);
+            const uint32_t m16 = spread3(cx >> 2) | (spread3(cy >> 2) << 1) | (spread3(cz >> 2) << 2);
+            key = (m16 << 9) | (dxq << 6) | (dyq << 3) | dzq;
+        } else if (L.sort_mode == 3) { // octant first, then the 64^3 cell
+            key = (oct << 18) | morton;
+        }
+        L.sort_keys[0][j] = key;
         L.sort_vals[0][j] = j;
     }
 }
