@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools_diag.py — development aid: run the -DRT_DIAG variant on the bench scene and print the wave-level census."""
 import importlib, os, sys
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 os.environ["RT_AMD_LIB"] = os.path.join(ROOT, "raytracing-course-hw-public_amd/csrc/variants/diag.so")
 rt = importlib.import_module("raytracing-course-hw-public_amd")
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 4

@@ -2,7 +2,7 @@
 """tools_diag_wf.py — development aid: wave-level census of wf_extend (-DRT_DIAG variant) on the bench scene."""
 import ctypes as C, importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 os.environ["RT_AMD_LIB"] = os.path.join(ROOT, "raytracing-course-hw-public_amd/csrc/variants/%s.so" % os.environ.get("RT_DIAG_VARIANT", "diag"))
 rt = importlib.import_module("raytracing-course-hw-public_amd")
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 4

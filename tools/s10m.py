@@ -2,7 +2,7 @@
 """tools_s10m.py — development aid: BASELINE config 5 shape (10M random triangles, 2048x2048) smoke/timing on one GPU."""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 rt = importlib.import_module("raytracing-course-hw-public_amd")
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 4

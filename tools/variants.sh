@@ -2,7 +2,7 @@
 # tools_variants.sh — build tuning variants of librt_amd.so into csrc/variants/<name>.so:  name:"-Dflags"
 # (development aid for kernel tuning; the shipped library is csrc/librt_amd.so)
 set -e
-cd "$(dirname "$0")/raytracing-course-hw-public_amd/csrc"
+cd "$(dirname "$0")/../raytracing-course-hw-public_amd/csrc"
 mkdir -p variants
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
