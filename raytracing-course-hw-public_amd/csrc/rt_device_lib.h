@@ -128,6 +128,10 @@ DEV void diag_add(int slot, unsigned long long v) {
 #define DIAG_LANES(slot) do { } while (0)
 #endif
 
+#ifdef RT_STAMP
+__device__ unsigned long long g_stamp[8]; // development build only: exposed load latency of node steps
+#endif
+
 // ---------------------------------------------------------------------------------------------- RNG policy
 template <int MODE> struct Rng;
 template <> struct Rng<RT_RNG_DEVICE> {
@@ -344,6 +348,9 @@ struct Trav {
     // newest frame (stack position sp-1) cached in registers: a pop followed by a node visit never waits for LDS
     uint32_t top_ref;
     float top_d, top_loc;
+#ifdef RT_STAMP
+    unsigned long long c_wait = 0, n_wait = 0; // development build only: exposed node-load latency
+#endif
 };
 DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
     T.o = o;
@@ -405,9 +412,20 @@ template <class STK> DEV void trav_pop(Trav &T, STK &stk) {
 template <bool STATS, class STK> DEV void trav_step_core(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
     const bool leaf = (T.cur & RT_LEAF_FLAG) != 0;
     const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (T.cur & RT_LEAF_BEGIN_MASK)) : reinterpret_cast<const float4 *>(bvh.nodes + T.cur);
+#ifdef RT_STAMP
+    const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+#endif
     const float4 r0 = p[0], r1 = p[1], r2 = p[2];
     if (!leaf) {
         const float4 r3 = p[3];
+#ifdef RT_STAMP
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long tl1 = __builtin_amdgcn_s_memtime();
+            T.c_wait += tl1 - tl0;
+            T.n_wait += 1;
+        }
+#endif
         st.node();
         st.box(2);
         // DevNode: lmin.xyz lmax.xyz rmin.xyz rmax.xyz left right

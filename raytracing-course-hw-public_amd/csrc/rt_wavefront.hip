@@ -295,6 +295,8 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
         atomicAdd(dg + 23, n_batch);
         atomicAdd(dg + 24, n_node);
         atomicAdd(dg + 25, 1ull);
+        atomicAdd(dg + 26, T.c_wait);
+        atomicAdd(dg + 27, T.n_wait);
     }
 #endif
     st.flush(L.stats);

@@ -39,6 +39,10 @@ class FramebufferGather:
         self.slab = torch.zeros(self.max_blocks * block * 3, dtype=torch.float32, device=device)
         self.gathered = [torch.empty_like(self.slab) for _ in range(world)] if (world > 1 and rank == 0) else None
         self.full = torch.zeros(self.nb * block * 3, dtype=torch.float32, device=device) if rank == 0 else None
+        import os
+
+        self.use_all_gather = os.environ.get("RT_GATHER", "gather") == "allgather"
+        self.all_slabs = None
 
     def gather(self, fb: torch.Tensor) -> Optional[torch.Tensor]:
         """Returns the assembled framebuffer (n_pix*3) on rank 0, None elsewhere."""
@@ -47,11 +51,20 @@ class FramebufferGather:
         self.padded[: self.n_pix * 3] = fb
         mine = self.padded.view(self.nb, self.block * 3)[self.rank :: self.world]
         self.slab[: mine.numel()] = mine.reshape(-1)
-        dist.gather(self.slab, self.gathered, dst=0)
-        if self.rank != 0:
-            return None
+        if self.use_all_gather:  # RT_GATHER=allgather: same bytes per link on a ring, every rank ends up with the slabs
+            if self.all_slabs is None:
+                self.all_slabs = torch.empty(self.world * self.slab.numel(), dtype=torch.float32, device=self.slab.device)
+            dist.all_gather_into_tensor(self.all_slabs, self.slab)
+            if self.rank != 0:
+                return None
+            parts = list(self.all_slabs.view(self.world, -1).unbind(0))
+        else:
+            dist.gather(self.slab, self.gathered, dst=0)
+            if self.rank != 0:
+                return None
+            parts = self.gathered
         fv = self.full.view(self.nb, self.block * 3)
         for r in range(self.world):
             k = len(range(r, self.nb, self.world))
-            fv[r :: self.world] = self.gathered[r][: k * self.block * 3].view(k, self.block * 3)
+            fv[r :: self.world] = parts[r][: k * self.block * 3].view(k, self.block * 3)
         return self.full[: self.n_pix * 3]

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W, H, SPP, BLOCK = 40, 37, 2, 256  # 1480 pixels: 6 blocks, the last one partial
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, mode):
+    os.environ["RT_GATHER"] = mode
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -40,11 +41,11 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gloo_sharded_render_equals_single_process(world, tmp_path, rt, oracle):
+@pytest.mark.parametrize("world,mode", [(2, "gather"), (3, "gather"), (2, "allgather")])
+def test_gloo_sharded_render_equals_single_process(world, mode, tmp_path, rt, oracle):
     port = 29500 + (os.getpid() + world) % 2000
     out = str(tmp_path / "full.npy")
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, mode), nprocs=world, join=True)
     got = np.load(out)
     sc = rt.scenegen.boxes_scene(n_boxes=6, seed=31, n_lights=2)
     ref, _ = oracle.OracleScene(sc).run_raytracer(W, H, SPP, seed=77)

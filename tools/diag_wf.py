@@ -15,7 +15,7 @@ lib = rt.lib(); lib.rt_debug_census.argtypes = [C.c_void_p, C.c_void_p]; lib.rt_
 _, st = dev.run_raytracer(1000, 1000, spp, seed=1, counters=True)
 lib.rt_debug_census(dev._h, out.ctypes.data)
 n = 1e6 * spp
-names = {12: "iterations", 13: "batches", 14: "batch_leaf_lanes", 15: "rounds", 16: "pairs", 17: "hit_path_execs", 18: "node_step_execs", 19: "node_step_lanes", 7: "pop_iters", 8: "pop_lanes", 2: "inner_execs", 3: "inner_lanes", 4: "seqtri_execs", 20: "cycles_batches", 21: "cycles_node_steps", 22: "cycles_total_iter", 23: "n_batches(stamp)", 24: "n_node_steps(stamp)", 25: "waves"}
+names = {12: "iterations", 13: "batches", 14: "batch_leaf_lanes", 15: "rounds", 16: "pairs", 17: "hit_path_execs", 18: "node_step_execs", 19: "node_step_lanes", 7: "pop_iters", 8: "pop_lanes", 2: "inner_execs", 3: "inner_lanes", 4: "seqtri_execs", 20: "cycles_batches", 21: "cycles_node_steps", 22: "cycles_total_iter", 23: "n_batches(stamp)", 24: "n_node_steps(stamp)", 25: "waves", 26: "node_load_wait_cycles(total so far)", 27: "node_load_waits"}
 for k, nm in sorted(names.items()):
     print(f"{nm:18s} {float(out[k]):.4g}  per-sample {float(out[k]) / n:.3f}")
 print("kernel_ms", st["kernel_ms"], "leaf lanes/batch", float(out[14]) / max(1, float(out[13])), "rounds/batch", float(out[15]) / max(1, float(out[13])),
