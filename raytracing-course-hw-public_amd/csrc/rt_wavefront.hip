@@ -41,7 +41,7 @@ using ExtStack = StackMemT<RT_EXT_LDS_DEPTH>;
 #define RT_EXT_POP_LOOP 1 /* 1: unwind with a loop inside the step (measured faster); 0: one frame per pass */
 #endif
 #ifndef RT_EXT_REFILL_MIN
-#define RT_EXT_REFILL_MIN 16 /* refill a wave's idle lanes once this many have finished */
+#define RT_EXT_REFILL_MIN 24 /* refill a wave's idle lanes once this many have finished (a refill stalls the wave on the ray loads) */
 #endif
 
 DEV uint32_t wf_global_pixel(const WfLaunch &L, uint32_t local_pixel) {
