@@ -256,9 +256,13 @@ def room_scene(
         tri = (centers[:, None, :] + offs).astype(np.float32)
         parts.append(tri)
         mats.append(rng.integers(2, 2 + n_materials, size=n_random).astype(np.uint32))
-    positions = np.concatenate(parts, axis=0).astype(np.float32)
+    if parts:
+        positions = np.concatenate(parts, axis=0).astype(np.float32)
+        material_ids = np.concatenate(mats, axis=0).astype(np.uint32)
+    else:  # the empty scene (bvh.h:373-376)
+        positions = np.zeros((0, 3, 3), dtype=np.float32)
+        material_ids = np.zeros(0, dtype=np.uint32)
     positions = positions + np.float32(0.0)  # canonicalise -0.0 -> +0.0 (identity node transform does that too)
-    material_ids = np.concatenate(mats, axis=0).astype(np.uint32)
     n = positions.shape[0]
     tex, tan = _default_attrs(n)
     if tex_size > 0:

@@ -204,6 +204,71 @@ def test_full_size_bench_scene_parity(gpu, oracle, sg):
     dev.close()
 
 
+def _cmp_render(gpu, oracle, sc, W=40, H=36, SPP=5, seed=3):
+    dev, orc = gpu.DeviceScene(sc), oracle.OracleScene(sc)
+    try:
+        for kw in ({}, {"megakernel": True}):
+            g, gs = dev.run_raytracer(W, H, SPP, seed=seed, counters=True, **kw)
+            o, os_ = orc.run_raytracer(W, H, SPP, seed=seed)
+            assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), kw
+            for k in ("casts", "nodes_visited", "box_tests", "tri_tests", "shaded_hits", "texel_fetches", "light_tri_tests"):
+                assert gs[k] == os_[k], (k, kw)
+        rays = random_rays(sc, 4000, seed=17) if sc.n_triangles else np.random.default_rng(1).normal(size=(100, 6)).astype(np.float32)
+        gp, gb = dev.cast_rays(rays)
+        op, ob = orc.cast_rays(rays)
+        assert np.array_equal(gp, op) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+        return g
+    finally:
+        dev.close()
+        orc.close()
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_small_ray_depths(gpu, oracle, sg, depth):
+    sc = sg.room_scene(300, seed=5, n_lights=3, n_materials=5, tex_size=8, n_tex_sets=2, alpha_fraction=0.3)
+    sc.ray_depth = depth
+    _cmp_render(gpu, oracle, sc)
+
+
+def test_empty_scene_renders_background(gpu, oracle, sg):
+    """No objects at all: BVH::build returns root = NO_CHILD (bvh.h:373-376); every sample is the white environment."""
+    sc = sg.room_scene(0, seed=1, n_lights=0, open_room=True)
+    assert sc.n_triangles == 0
+    fb = _cmp_render(gpu, oracle, sc)
+    assert np.array_equal(fb, np.ones_like(fb))
+
+
+def test_big_leaves_and_duplicate_geometry(gpu, oracle, sg):
+    """Many triangles with identical centroids: the SAH sweep finds no split (bvh.h:299-312), so leaves hold dozens of
+    triangles (walked with the per-triangle flags instead of the cooperative <= 8 path) and equal-t hits occur: the
+    first triangle in leaf order must win (bvh.h:132)."""
+    sc = sg.boxes_scene(n_boxes=5, seed=8, n_lights=2)
+    tri = sc.positions[20:21]
+    dup = np.repeat(tri, 40, axis=0)
+    sc.positions = np.concatenate([sc.positions, dup, dup * np.float32(1.0)], axis=0).astype(np.float32)
+    n = sc.positions.shape[0]
+    sc.material_ids = np.concatenate([sc.material_ids, np.full(80, 3, dtype=np.uint32)])
+    sc.texcoords = np.zeros((n, 3, 2), dtype=np.float32)
+    sc.tangents = np.zeros((n, 3, 3), dtype=np.float32)
+    sc.tangents[..., 0] = 1
+    dev = gpu.DeviceScene(sc)
+    info = dev.bvh_info(0)
+    leaf_sizes = (info["nodes"][:, 9] - info["nodes"][:, 8])[info["nodes"][:, 6] == 0xFFFFFFFF]
+    assert leaf_sizes.max() > 8, "the test needs a leaf beyond the cooperative limit"
+    dev.close()
+    _cmp_render(gpu, oracle, sc)
+
+
+def test_single_texel_textures_skip_gamma(gpu, oracle, sg):
+    """1x1 loaded textures take Texture::sample's fast path and are returned WITHOUT gamma (geometry.h:548-550)."""
+    sc = sg.room_scene(200, seed=9, n_lights=2, n_materials=4, tex_size=0)
+    sc.textures = [np.array([[[200, 100, 50, 255]]], dtype=np.uint8), np.array([[[128, 128, 255, 255]]], dtype=np.uint8), np.array([[[0, 180, 90, 255]]], dtype=np.uint8)]
+    for m in sc.materials[2:]:
+        m.color_tex, m.normal_tex, m.metallic_roughness_tex = 0, 1, 2
+    sc.texcoords = np.random.default_rng(2).uniform(-3, 3, size=sc.texcoords.shape).astype(np.float32)
+    _cmp_render(gpu, oracle, sc)
+
+
 def test_shard_union_equals_single(pairs, gpu):
     """Image-row tiles sharded over G ranks: the union of the shards is bit-identical to one GPU."""
     dev, _, _ = pairs["room_plain"]
