@@ -37,6 +37,16 @@ namespace {
 #define RT_EXT_LDS_DEPTH 6 /* LDS part of the traversal stack in wf_extend: 6 -> 26 KB/block -> 6 blocks (24 waves) per CU */
 #endif
 using ExtStack = StackMemT<RT_EXT_LDS_DEPTH>;
+#ifndef RT_SHADE_WAVES_PER_SIMD
+#define RT_SHADE_WAVES_PER_SIMD 4
+#endif
+#ifndef RT_SHADE_LDS_DEPTH
+#define RT_SHADE_LDS_DEPTH 4 /* only the light-BVH traversal of bvh_mix_dist::pdf uses a stack in wf_shade */
+#endif
+using ShadeStack = StackMemT<RT_SHADE_LDS_DEPTH>;
+#ifndef RT_EXT_CHUNK
+#define RT_EXT_CHUNK 128u /* queue positions a wave takes per ticket atomic */
+#endif
 #ifndef RT_EXT_POP_LOOP
 #define RT_EXT_POP_LOOP 1 /* 1: unwind with a loop inside the step (measured faster); 0: one frame per pass */
 #endif
@@ -200,6 +210,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
     T.sp = 0;
     uint32_t slot = RT_NONE;
     bool exhausted = n_in == 0; // wave-uniform
+    uint32_t q_lo = 0, q_hi = 0; // this wave's private range of queue positions
 #ifdef RT_STAMP
     unsigned long long t_loop = __builtin_amdgcn_s_memtime(), c_batch = 0, c_node = 0, c_total = 0, n_batch = 0, n_node = 0;
 #endif
@@ -208,25 +219,31 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
         const unsigned long long im = __ballot(idle);
         const int n_idle = __popcll(im);
         if (!exhausted && (n_idle >= RT_EXT_REFILL_MIN || n_idle == (int)__popcll(__ballot(1)))) {
-            // refill: ballot + prefix count, one ticket atomic for the whole wave
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
-            uint32_t base = 0;
-            if (idle && rank == 0)
-                base = atomicAdd(L.counters + WF_CNT_TICKET, (uint32_t)n_idle);
-            base = __builtin_amdgcn_readfirstlane(__shfl(base, __ffsll((long long)im) - 1));
-            exhausted = base + (uint32_t)n_idle >= n_in;
-            if (idle) {
-                const uint32_t jq = base + rank;
-                if (jq < n_in) {
-                    const uint32_t j = L.order ? L.order[jq] : jq; // coherence-sorted processing order
-                    const float4 *rq = reinterpret_cast<const float4 *>(L.rays_in + j);
-                    const float4 r0 = rq[0], r1 = rq[1];
-                    slot = j;
-                    trav_init(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y));
-                    if (T.cur == T_DONE) // no geometry at all: immediate miss
-                        *reinterpret_cast<float4 *>(L.hits + j) = make_float4(__uint_as_float(RT_NONE), 0.f, 0.f, 0.f);
-                }
+            // refill from the wave's private ticket range [q_lo, q_hi); a new range of RT_EXT_CHUNK queue positions is
+            // taken with ONE atomic when it runs dry (a single ticket word saturates near 90 M atomics/s, so tickets
+            // are taken per chunk, not per refill)
+            if (q_lo == q_hi) {
+                uint32_t base = 0;
+                if ((threadIdx.x & 63u) == 0u)
+                    base = atomicAdd(L.counters + WF_CNT_TICKET, (uint32_t)RT_EXT_CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base);
+                q_lo = base < n_in ? base : n_in;
+                q_hi = base + RT_EXT_CHUNK < n_in ? base + RT_EXT_CHUNK : n_in;
+                exhausted = q_lo == q_hi; // the queue is used up
             }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+            const uint32_t avail = q_hi - q_lo;
+            if (idle && rank < avail) {
+                const uint32_t jq = q_lo + rank;
+                const uint32_t j = L.order ? L.order[jq] : jq; // coherence-sorted processing order
+                const float4 *rq = reinterpret_cast<const float4 *>(L.rays_in + j);
+                const float4 r0 = rq[0], r1 = rq[1];
+                slot = j;
+                trav_init(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y));
+                if (T.cur == T_DONE) // no geometry at all: immediate miss
+                    *reinterpret_cast<float4 *>(L.hits + j) = make_float4(__uint_as_float(RT_NONE), 0.f, 0.f, 0.f);
+            }
+            q_lo += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
         }
         DIAG(12, 1);
 #if !RT_EXT_POP_LOOP
@@ -303,15 +320,15 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
 }
 
 // ------------------------------------------------------------------------------------------------ shade
-template <bool STATS> __global__ __launch_bounds__(256, 4) void wf_shade(const DevScene S, const WfLaunch L) {
+template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD) void wf_shade(const DevScene S, const WfLaunch L) {
     __shared__ float s_lin[256];
     __shared__ float s_gam[256];
-    __shared__ uint32_t s_stack[STACK_LDS_DWORDS];
+    __shared__ uint32_t s_stack[STACK_LDS_DWORDS_FOR(RT_SHADE_LDS_DEPTH)];
     s_lin[threadIdx.x] = S.lut_linear[threadIdx.x];
     s_gam[threadIdx.x] = S.lut_gamma[threadIdx.x];
     __syncthreads();
     LaneStats<STATS> st;
-    StackMem stk;
+    ShadeStack stk;
     stk.lds = s_stack + threadIdx.x;
     const bool has_lights = S.lights.n_tris != 0; // raytracer.h:449-453
     const uint32_t n_in = L.counters[WF_CNT_IN];
