@@ -27,6 +27,13 @@ void rt_loaded_free(rt_loaded_scene *s);
  * main.cpp:40-41. */
 int rt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb8);
 
+/* BVH::build(objs, pred) (bvh.h:368-393) on the host, without a GPU: the same builder rt_create uses (reference topology,
+ * subtrees built in parallel). `subset` = original indices of the triangles that pass the predicate, in scene order.
+ * Output as rt_bvh_info: 10 words per node in the reference's pre-order numbering + the object permutation. The node
+ * buffer must hold 2*n_subset + 1 nodes. */
+int rt_bvh_build_host(const float *positions, uint32_t n_triangles, const uint32_t *subset, uint32_t n_subset, uint32_t *n_nodes, uint32_t *root,
+                      uint32_t *nodes_out, uint32_t *order_out);
+
 /* PNG (8-bit, non-interlaced) -> RGBA8, the subset of stb_image the fixtures need. Caller frees with rt_free. */
 int rt_png_decode_file(const char *path, uint32_t *w, uint32_t *h, uint8_t **rgba8);
 void rt_free(void *p);

@@ -181,6 +181,20 @@ class DeviceScene:
         return {"root": root.value, "nodes": nodes, "order": order}
 
 
+def bvh_build_host(positions: np.ndarray, subset: Optional[np.ndarray] = None) -> dict:
+    """BVH::build (bvh.h:368-393) with the library's host builder, no GPU needed: {root, nodes (n,10) u32, order}."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 9)
+    n = pos.shape[0]
+    sub = np.arange(n, dtype=np.uint32) if subset is None else np.ascontiguousarray(subset, dtype=np.uint32)
+    nodes = np.zeros((2 * len(sub) + 1, 10), dtype=np.uint32)
+    order = np.zeros(len(sub), dtype=np.uint32)
+    nn, root = C.c_uint32(), C.c_uint32()
+    rc = lib().rt_bvh_build_host(fptr(pos), n, u32ptr(sub), len(sub), C.byref(nn), C.byref(root), u32ptr(nodes), u32ptr(order))
+    if rc != RT_OK:
+        raise RtError(rc, "rt_bvh_build_host")
+    return {"root": root.value, "nodes": nodes[: nn.value].copy(), "order": order}
+
+
 def tonemap(fb: np.ndarray) -> np.ndarray:
     """Image::set_pixel's convert_color (image.h:40-42, 79-82) over a whole linear framebuffer -> (H,W,3) u8."""
     fb = np.ascontiguousarray(fb, dtype=np.float32)

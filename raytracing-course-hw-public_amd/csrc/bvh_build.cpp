@@ -17,6 +17,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
+#include <future>
+#include <thread>
 
 namespace rt {
 namespace {
@@ -50,10 +53,16 @@ struct Keyed {
     uint32_t idx;
 };
 
-struct Builder {
-    const float *pos;
-    std::vector<Box> tri_box;      // per original triangle
-    std::vector<float> center[3];  // triangle::center() geometry.h:485-487
+struct BuildData { // read-only while building
+    std::vector<Box> tri_box;     // per original triangle
+    std::vector<float> center[3]; // triangle::center() geometry.h:485-487
+};
+
+struct Builder { // one per worker thread: own node list and scratch, shared BuildData
+    const BuildData &data;
+    const std::vector<Box> &tri_box;
+    const std::vector<float> (&center)[3];
+    explicit Builder(const BuildData &d) : data(d), tri_box(d.tri_box), center(d.center) {}
     std::vector<HostNode> nodes;
     std::vector<float> pref, suf;
     std::vector<Keyed> scratch;
@@ -136,31 +145,83 @@ struct Builder {
 
 } // namespace
 
+// Subtrees are independent once a node has been split, so the top of the tree is built with one task per subtree
+// (std::async) and the node lists are concatenated in the reference's pre-order numbering afterwards: parent, whole
+// left subtree, whole right subtree (bvh.h:351-363). Every split still runs the sequential std::sort on its own slice, so
+// topology and object order are bit-identical to the single-threaded (and the reference's) build.
+static std::vector<HostNode> build_parallel(const BuildData &data, uint32_t offset, uint32_t *objs, size_t n, const Box &box, uint32_t depth_left,
+                                            int par_levels) {
+    Builder w(data);
+    if (par_levels <= 0 || n < 65536) {
+        w.build(offset, objs, n, box, 4, depth_left);
+        return std::move(w.nodes);
+    }
+    HostNode nd;
+    std::memcpy(nd.lo, box.lo, sizeof(nd.lo));
+    std::memcpy(nd.hi, box.hi, sizeof(nd.hi));
+    nd.left = nd.right = RT_NONE;
+    nd.obj_begin = offset;
+    nd.obj_end = (uint32_t)(offset + n);
+    size_t mid = n;
+    if (depth_left != 0)
+        mid = w.split(objs, n, box);
+    const size_t nl = mid, nr = n - mid;
+    if (depth_left == 0 || nl == 0 || nr == 0 || (nl < 4 && nr < 4)) // leaf rules of bvh.h:336-346
+        return {nd};
+    nd.obj_begin = nd.obj_end = 0;
+    const Box lb = w.bounds_of(objs, nl), rb = w.bounds_of(objs + nl, nr);
+    auto left_task = std::async(std::launch::async, build_parallel, std::cref(data), offset, objs, nl, lb, depth_left - 1, par_levels - 1);
+    std::vector<HostNode> right = build_parallel(data, (uint32_t)(offset + nl), objs + nl, nr, rb, depth_left - 1, par_levels - 1);
+    std::vector<HostNode> left = left_task.get();
+    std::vector<HostNode> out;
+    out.reserve(1 + left.size() + right.size());
+    nd.left = 1;
+    nd.right = (uint32_t)(1 + left.size());
+    out.push_back(nd);
+    auto append = [&out](const std::vector<HostNode> &blk) {
+        const uint32_t shift = (uint32_t)out.size();
+        for (HostNode c : blk) {
+            if (c.left != RT_NONE)
+                c.left += shift;
+            if (c.right != RT_NONE)
+                c.right += shift;
+            out.push_back(c);
+        }
+    };
+    append(left);
+    append(right);
+    return out;
+}
+
 HostBvh build_bvh(const float *positions, uint32_t n_total, const std::vector<uint32_t> &subset) {
     HostBvh out;
     if (n_total == 0) { // bvh.h:373-376
         out.root = RT_NONE;
         return out;
     }
-    Builder b;
-    b.pos = positions;
-    b.tri_box.resize(n_total);
+    BuildData data;
+    data.tri_box.resize(n_total);
     for (int k = 0; k < 3; ++k)
-        b.center[k].resize(n_total);
+        data.center[k].resize(n_total);
     for (uint32_t t : subset) {
         const float *p = positions + 9 * (size_t)t;
         Box bx; // triangle::bounding_box geometry.h:489-495
         bx.extend_point(p);
         bx.extend_point(p + 3);
         bx.extend_point(p + 6);
-        b.tri_box[t] = bx;
+        data.tri_box[t] = bx;
         for (int k = 0; k < 3; ++k)
-            b.center[k][t] = (p[k] + p[3 + k] + p[6 + k]) / 3;
+            data.center[k][t] = (p[k] + p[3 + k] + p[6 + k]) / 3;
     }
     out.order = subset;
+    Builder b(data);
     Box root_box = b.bounds_of(out.order.data(), out.order.size());
-    out.root = b.build(0, out.order.data(), out.order.size(), root_box, 4, 64);
-    out.nodes = std::move(b.nodes);
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    int par_levels = 0;
+    while ((1u << par_levels) < hw && par_levels < 6)
+        ++par_levels;
+    out.nodes = build_parallel(data, 0, out.order.data(), out.order.size(), root_box, 64, par_levels);
+    out.root = 0;
     return out;
 }
 
@@ -228,3 +289,25 @@ FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions) {
 }
 
 } // namespace rt
+
+extern "C" int rt_bvh_build_host(const float *positions, uint32_t n_triangles, const uint32_t *subset, uint32_t n_subset, uint32_t *n_nodes, uint32_t *root,
+                                 uint32_t *nodes_out, uint32_t *order_out) {
+    if ((n_triangles && !positions) || (n_subset && !subset) || !n_nodes || !root)
+        return 1; // RT_ERR_INVALID_ARG
+    std::vector<uint32_t> sub(subset, subset + n_subset);
+    rt::HostBvh b = rt::build_bvh(positions, n_triangles, sub);
+    *n_nodes = (uint32_t)b.nodes.size();
+    *root = b.root;
+    if (nodes_out)
+        for (size_t i = 0; i < b.nodes.size(); ++i) {
+            std::memcpy(nodes_out + 10 * i, b.nodes[i].lo, 12);
+            std::memcpy(nodes_out + 10 * i + 3, b.nodes[i].hi, 12);
+            nodes_out[10 * i + 6] = b.nodes[i].left;
+            nodes_out[10 * i + 7] = b.nodes[i].right;
+            nodes_out[10 * i + 8] = b.nodes[i].obj_begin;
+            nodes_out[10 * i + 9] = b.nodes[i].obj_end;
+        }
+    if (order_out && !b.order.empty())
+        std::memcpy(order_out, b.order.data(), b.order.size() * sizeof(uint32_t));
+    return 0;
+}

@@ -122,6 +122,32 @@ def test_oracle_ppm_byte_identical_to_reference(oracles, oracle, rt, name, tmp_p
     assert st["samples"] == W * H * SPP
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_product_host_bvh_builder_matches_reference(rt, loaded, name):
+    """The product's own builder (csrc/bvh_build.cpp, what rt_create uploads) against the reference's BVH dump."""
+    ls, sc, _ = loaded[name]
+    g = gold(name)
+    a = ls.arrays()
+    b = rt.bvh_build_host(a["positions"])
+    assert b["root"] == int(g["scene_root"])
+    assert np.array_equal(b["nodes"], g["scene_nodes"]) and np.array_equal(b["order"], g["scene_order"])
+    lights = np.array([i for i, m in enumerate(a["material_ids"]) if np.any(a["materials"][int(m)]["emission"] != 0)], dtype=np.uint32)
+    bl = rt.bvh_build_host(a["positions"], lights)
+    assert np.array_equal(bl["nodes"], g["light_nodes"]) and np.array_equal(bl["order"], g["light_order"])
+
+
+def test_parallel_subtree_build_is_bit_identical(rt, sg, oracle):
+    """Above 65 536 triangles the builder splits the top of the tree into parallel tasks; node numbering, boxes and the
+    object permutation must still equal the (sequential, literal) oracle build."""
+    sc = sg.room_scene(150000, seed=3, n_lights=8, tex_size=0)
+    b = rt.bvh_build_host(sc.positions)
+    ob = oracle.OracleScene(sc).bvh_info(0)
+    assert b["root"] == ob["root"]
+    assert np.array_equal(b["nodes"], ob["nodes"]) and np.array_equal(b["order"], ob["order"])
+    leaves = b["nodes"][b["nodes"][:, 6] == 0xFFFFFFFF]
+    assert (leaves[:, 9] - leaves[:, 8]).sum() == sc.n_triangles
+
+
 def test_oracle_thread_count_does_not_change_the_image(oracles, rt):
     a, _ = oracles["room_plain"].run_raytracer(W, H, 2, rng_mode=rt.RT_RNG_REFERENCE, threads=1)
     b, _ = oracles["room_plain"].run_raytracer(W, H, 2, rng_mode=rt.RT_RNG_REFERENCE, threads=7)
