@@ -128,9 +128,6 @@ DEV void diag_add(int slot, unsigned long long v) {
 #define DIAG_LANES(slot) do { } while (0)
 #endif
 
-#ifdef RT_STAMP
-__device__ unsigned long long g_stamp[8]; // development build only: exposed load latency of node steps
-#endif
 
 // ---------------------------------------------------------------------------------------------- RNG policy
 template <int MODE> struct Rng;
@@ -200,25 +197,6 @@ DEV bool box_hit_exact(V3 bmin, V3 bmax, V3 o, V3 d, float min_dst, float &dist)
 // select forms up to the sign of a zero, which cannot reach the result: t_min/t_max are only compared, and
 // max(t_min, min_dst) with min_dst = 1e-4 > 0 never returns a zero.
 DEV bool box_hit_fast(V3 bmin, V3 bmax, V3 o, V3 d, V3 r, float min_dst, float &dist) {
-#ifdef RT_ABLATE_PAD /* timing experiment only: RT_ABLATE_PAD extra VALU instructions per box test, results unchanged */
-    {
-        float pad = bmin.x;
-#pragma unroll
-        for (int i = 0; i < RT_ABLATE_PAD; ++i)
-            asm volatile("v_mov_b32 %0, %0" : "+v"(pad));
-        if (pad != bmin.x)
-            dist = pad;
-    }
-#endif
-#ifdef RT_ABLATE_BOX /* timing experiment only: cheap inexact slab test, wrong images */
-    {
-        V3 q1 = (bmin - o) * r, q2 = (bmax - o) * r;
-        float tn = fmaxf(fmaxf(fminf(q1.x, q2.x), fminf(q1.y, q2.y)), fminf(q1.z, q2.z));
-        float tx = fminf(fminf(fmaxf(q1.x, q2.x), fmaxf(q1.y, q2.y)), fmaxf(q1.z, q2.z));
-        dist = fmaxf(tn, min_dst);
-        return (tn <= tx) & (tx >= min_dst);
-    }
-#endif
     V3 a1 = bmin - o, a2 = bmax - o;
     float q1x = div_exact_fast(a1.x, d.x, r.x), q1y = div_exact_fast(a1.y, d.y, r.y), q1z = div_exact_fast(a1.z, d.z, r.z);
     float q2x = div_exact_fast(a2.x, d.x, r.x), q2y = div_exact_fast(a2.y, d.y, r.y), q2z = div_exact_fast(a2.z, d.z, r.z);
@@ -239,9 +217,6 @@ DEV bool box_hit_fast(V3 bmin, V3 bmax, V3 o, V3 d, V3 r, float min_dst, float &
 // Anything else ("maybe") takes the reference's three IEEE divisions and its exact comparisons, so the filter only
 // removes work, never changes an outcome. NaN/inf operands make every comparison false -> "maybe".
 DEV bool tri_hit(V3 ta, V3 av, V3 au, V3 o, V3 d, float min_dst, V3 &xs_out) {
-#ifdef RT_ABLATE_TRI /* timing experiment only: wrong images */
-    return (ta.x + o.x) == 12345.678f;
-#endif
     V3 at = -d;
     V3 y = o - ta;
     V3 c_ut = crs(au, at);
@@ -348,9 +323,6 @@ struct Trav {
     // newest frame (stack position sp-1) cached in registers: a pop followed by a node visit never waits for LDS
     uint32_t top_ref;
     float top_d, top_loc;
-#ifdef RT_STAMP
-    unsigned long long c_wait = 0, n_wait = 0; // development build only: exposed node-load latency
-#endif
 };
 DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
     T.o = o;
@@ -412,20 +384,9 @@ template <class STK> DEV void trav_pop(Trav &T, STK &stk) {
 template <bool STATS, class STK> DEV void trav_step_core(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
     const bool leaf = (T.cur & RT_LEAF_FLAG) != 0;
     const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (T.cur & RT_LEAF_BEGIN_MASK)) : reinterpret_cast<const float4 *>(bvh.nodes + T.cur);
-#ifdef RT_STAMP
-    const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
-#endif
     const float4 r0 = p[0], r1 = p[1], r2 = p[2];
     if (!leaf) {
         const float4 r3 = p[3];
-#ifdef RT_STAMP
-        {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned long long tl1 = __builtin_amdgcn_s_memtime();
-            T.c_wait += tl1 - tl0;
-            T.n_wait += 1;
-        }
-#endif
         st.node();
         st.box(2);
         // DevNode: lmin.xyz lmax.xyz rmin.xyz rmax.xyz left right

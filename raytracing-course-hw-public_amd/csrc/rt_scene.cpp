@@ -76,6 +76,7 @@ struct rt_scene {
     uint32_t *wf_sort_keys[2] = {nullptr, nullptr}, *wf_sort_vals[2] = {nullptr, nullptr};
     void *wf_sort_temp = nullptr;
     size_t wf_sort_temp_bytes = 0;
+    uint32_t *wf_host_count = nullptr; // pinned
 
     int ensure_wavefront(uint64_t paths, uint64_t pixels, uint32_t depth) {
         if (paths <= wf_paths_cap && pixels <= wf_pixels_cap && depth <= wf_depth_cap)
@@ -114,6 +115,8 @@ struct rt_scene {
 
     ~rt_scene() {
         (void)hipSetDevice(device);
+        if (wf_host_count)
+            (void)hipHostFree(wf_host_count);
         for (void *p : wf_owned)
             (void)hipFree(p);
         for (void *p : owned)
@@ -438,6 +441,9 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
             W.sort_keys[k] = sort_rays ? s->wf_sort_keys[k] : nullptr;
             W.sort_vals[k] = sort_rays ? s->wf_sort_vals[k] : nullptr;
         }
+        if (!s->wf_host_count && hipHostMalloc((void **)&s->wf_host_count, sizeof(uint32_t)) != hipSuccess)
+            s->wf_host_count = nullptr;
+        W.host_count = s->wf_host_count;
         W.sort_temp = s->wf_sort_temp;
         W.sort_mode = sort_env ? (uint32_t)std::atoi(sort_env) : 1u;
         W.sort_temp_bytes = s->wf_sort_temp_bytes;

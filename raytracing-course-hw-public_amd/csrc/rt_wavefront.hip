@@ -211,9 +211,6 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
     uint32_t slot = RT_NONE;
     bool exhausted = n_in == 0; // wave-uniform
     uint32_t q_lo = 0, q_hi = 0; // this wave's private range of queue positions
-#ifdef RT_STAMP
-    unsigned long long t_loop = __builtin_amdgcn_s_memtime(), c_batch = 0, c_node = 0, c_total = 0, n_batch = 0, n_node = 0;
-#endif
     for (;;) {
         const bool idle = T.cur == T_DONE;
         const unsigned long long im = __ballot(idle);
@@ -269,10 +266,6 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
                 break;
             continue;
         }
-#ifdef RT_STAMP
-        const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
-        const bool did_batch = (sm == 0ull || __popcll(lm) >= RT_EXT_LEAF_MIN);
-#endif
         if (sm == 0ull || __popcll(lm) >= RT_EXT_LEAF_MIN) {
             leaf_batch<STATS>(T, S.scene, stk, at_leaf, s_owner, s_min, s_bc, st);
         } else if (stepper) {
@@ -286,36 +279,9 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
                 trav_pop_once(T, stk);
 #endif
         }
-#ifdef RT_STAMP
-        {
-            const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
-            if (did_batch) {
-                c_batch += tq1 - tq0;
-                n_batch += 1;
-            } else {
-                c_node += tq1 - tq0;
-                n_node += 1;
-            }
-            c_total += tq1 - t_loop;
-            t_loop = tq1;
-        }
-#endif
         if (active && T.cur == T_DONE)
             *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
     }
-#ifdef RT_STAMP
-    if ((threadIdx.x & 63u) == 0u) { // development build only: per-wave cycle sums -> census words 20..25
-        unsigned long long *dg = reinterpret_cast<unsigned long long *>(L.diag);
-        atomicAdd(dg + 20, c_batch);
-        atomicAdd(dg + 21, c_node);
-        atomicAdd(dg + 22, c_total);
-        atomicAdd(dg + 23, n_batch);
-        atomicAdd(dg + 24, n_node);
-        atomicAdd(dg + 25, 1ull);
-        atomicAdd(dg + 26, T.c_wait);
-        atomicAdd(dg + 27, T.n_wait);
-    }
-#endif
     st.flush(L.stats);
 }
 
@@ -508,9 +474,7 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         hipLaunchKernelGGL((wf_generate<false>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
     const int ext_blocks = num_cus * 8;
     const int shade_blocks = num_cus * 8;
-    static uint32_t *h_count = nullptr; // pinned word for the per-bounce queue size read-back
-    if (L.sort_keys[0] && !h_count && hipHostMalloc((void **)&h_count, sizeof(uint32_t)) != hipSuccess)
-        h_count = nullptr;
+    uint32_t *h_count = L.host_count; // pinned word owned by the scene: per-bounce queue size read-back
     uint32_t n_active = L.n_paths;
     for (uint32_t b = 0; b < L.ray_depth; ++b) {
         L.order = nullptr;
