@@ -265,9 +265,12 @@ struct Hit {
 constexpr int LDS_DEPTH = RT_LDS_DEPTH;
 template <int LDS_DEPTH> struct StackMemT {
     uint32_t *lds; // [3][LDS_DEPTH][256] dwords, this thread's column starts at lds + threadIdx.x
-    uint32_t ov_ref[RT_MAX_STACK - LDS_DEPTH];
-    float ov_d[RT_MAX_STACK - LDS_DEPTH];
-    float ov_loc[RT_MAX_STACK - LDS_DEPTH];
+    // The struct holds POINTERS only (registers after scalar replacement): with the arrays as members the whole object,
+    // `lds` included, lived in scratch and every LDS access became a generic flat_load/flat_store behind a scratch load
+    // of the pointer. RT_DECLARE_STACK sets the pointers up from a __shared__ array and per-lane overflow arrays.
+    uint32_t *ov_ref; // [RT_MAX_STACK - LDS_DEPTH], per-lane scratch
+    float *ov_d;
+    float *ov_loc;
     DEV void push(int sp, uint32_t ref, float d, float loc) {
         if (sp < LDS_DEPTH) {
             lds[(0 * LDS_DEPTH + sp) * 256] = ref;
@@ -299,9 +302,56 @@ template <int LDS_DEPTH> struct StackMemT {
     }
     DEV uint32_t pop_ref(int sp) { return sp < LDS_DEPTH ? lds[(0 * LDS_DEPTH + sp) * 256] : ov_ref[sp - LDS_DEPTH]; }
 };
-using StackMem = StackMemT<LDS_DEPTH>;
+// Array-member variant (the whole object lives in scratch; LDS accesses go through generic pointers). Kept for the
+// parity megakernel and the probe kernels of rt_kernels.hip, where the pointer-only form trips a gfx950 backend error
+// ("Operand has incorrect register class", ROCm 7.2); those kernels are not on the timed path.
+template <int LDS_DEPTH> struct StackMemArrT {
+    uint32_t *lds;
+    uint32_t ov_ref[RT_MAX_STACK - LDS_DEPTH];
+    float ov_d[RT_MAX_STACK - LDS_DEPTH];
+    float ov_loc[RT_MAX_STACK - LDS_DEPTH];
+    DEV void push(int sp, uint32_t ref, float d, float loc) {
+        if (sp < LDS_DEPTH) {
+            lds[(0 * LDS_DEPTH + sp) * 256] = ref;
+            lds[(1 * LDS_DEPTH + sp) * 256] = __float_as_uint(d);
+            lds[(2 * LDS_DEPTH + sp) * 256] = __float_as_uint(loc);
+        } else {
+            ov_ref[sp - LDS_DEPTH] = ref;
+            ov_d[sp - LDS_DEPTH] = d;
+            ov_loc[sp - LDS_DEPTH] = loc;
+        }
+    }
+    DEV void pop(int sp, uint32_t &ref, float &d, float &loc) {
+        if (sp < LDS_DEPTH) {
+            ref = lds[(0 * LDS_DEPTH + sp) * 256];
+            d = __uint_as_float(lds[(1 * LDS_DEPTH + sp) * 256]);
+            loc = __uint_as_float(lds[(2 * LDS_DEPTH + sp) * 256]);
+        } else {
+            ref = ov_ref[sp - LDS_DEPTH];
+            d = ov_d[sp - LDS_DEPTH];
+            loc = ov_loc[sp - LDS_DEPTH];
+        }
+    }
+    DEV void push_ref(int sp, uint32_t ref) {
+        if (sp < LDS_DEPTH)
+            lds[(0 * LDS_DEPTH + sp) * 256] = ref;
+        else
+            ov_ref[sp - LDS_DEPTH] = ref;
+    }
+    DEV uint32_t pop_ref(int sp) { return sp < LDS_DEPTH ? lds[(0 * LDS_DEPTH + sp) * 256] : ov_ref[sp - LDS_DEPTH]; }
+};
+using StackMem = StackMemArrT<LDS_DEPTH>;
 #define STACK_LDS_DWORDS (3 * LDS_DEPTH * 256)
 #define STACK_LDS_DWORDS_FOR(depth) (3 * (depth) * 256)
+#define RT_DECLARE_STACK(NAME, DEPTH, SHARED_ARRAY)          \
+    uint32_t NAME##_ov_ref[RT_MAX_STACK - (DEPTH)];         \
+    float NAME##_ov_d[RT_MAX_STACK - (DEPTH)];              \
+    float NAME##_ov_loc[RT_MAX_STACK - (DEPTH)];            \
+    StackMemT<(DEPTH)> NAME;                                \
+    NAME.lds = (SHARED_ARRAY) + threadIdx.x;                \
+    NAME.ov_ref = NAME##_ov_ref;                            \
+    NAME.ov_d = NAME##_ov_d;                                \
+    NAME.ov_loc = NAME##_ov_loc
 
 // ---------------------------------------------------------------------------------------------- closest hit
 // BVH::intersect_ray (bvh.h:170-180, 195-235) as a resumable per-lane state machine: one call of trav_step visits

@@ -198,8 +198,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
     unsigned long long *s_min = s_min_all[wave];
     float2 *s_bc = s_bc_all[wave];
     LaneStats<STATS> st;
-    ExtStack stk;
-    stk.lds = s_stack + threadIdx.x;
+    RT_DECLARE_STACK(stk, RT_EXT_LDS_DEPTH, s_stack);
 #ifdef RT_DIAG
     if (STATS && threadIdx.x == 0 && blockIdx.x == 0)
         g_diag = (DevStats *)L.diag;
@@ -294,8 +293,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
     s_gam[threadIdx.x] = S.lut_gamma[threadIdx.x];
     __syncthreads();
     LaneStats<STATS> st;
-    ShadeStack stk;
-    stk.lds = s_stack + threadIdx.x;
+    RT_DECLARE_STACK(stk, RT_SHADE_LDS_DEPTH, s_stack);
     const bool has_lights = S.lights.n_tris != 0; // raytracer.h:449-453
     const uint32_t n_in = L.counters[WF_CNT_IN];
     const uint32_t stride = gridDim.x * blockDim.x;
