@@ -283,11 +283,13 @@ template <int LDS_DEPTH> struct StackMemT {
         }
     }
     DEV void pop(int sp, uint32_t &ref, float &d, float &loc) {
-        if (sp < LDS_DEPTH) {
-            ref = lds[(0 * LDS_DEPTH + sp) * 256];
-            d = __uint_as_float(lds[(1 * LDS_DEPTH + sp) * 256]);
-            loc = __uint_as_float(lds[(2 * LDS_DEPTH + sp) * 256]);
-        } else {
+        // The LDS read is unconditional (clamped slot) and the rare deep entry overrides it: selecting between an LDS and
+        // a scratch POINTER would turn both into one generic flat_load.
+        const int slot = sp < LDS_DEPTH ? sp : LDS_DEPTH - 1;
+        ref = lds[(0 * LDS_DEPTH + slot) * 256];
+        d = __uint_as_float(lds[(1 * LDS_DEPTH + slot) * 256]);
+        loc = __uint_as_float(lds[(2 * LDS_DEPTH + slot) * 256]);
+        if (sp >= LDS_DEPTH) {
             ref = ov_ref[sp - LDS_DEPTH];
             d = ov_d[sp - LDS_DEPTH];
             loc = ov_loc[sp - LDS_DEPTH];
@@ -300,7 +302,12 @@ template <int LDS_DEPTH> struct StackMemT {
         else
             ov_ref[sp - LDS_DEPTH] = ref;
     }
-    DEV uint32_t pop_ref(int sp) { return sp < LDS_DEPTH ? lds[(0 * LDS_DEPTH + sp) * 256] : ov_ref[sp - LDS_DEPTH]; }
+    DEV uint32_t pop_ref(int sp) {
+        uint32_t ref = lds[(0 * LDS_DEPTH + (sp < LDS_DEPTH ? sp : LDS_DEPTH - 1)) * 256];
+        if (sp >= LDS_DEPTH)
+            ref = ov_ref[sp - LDS_DEPTH];
+        return ref;
+    }
 };
 // Array-member variant (the whole object lives in scratch; LDS accesses go through generic pointers). Kept for the
 // parity megakernel and the probe kernels of rt_kernels.hip, where the pointer-only form trips a gfx950 backend error
