@@ -8,9 +8,10 @@ SURVEY.md 8d: 262 144 random triangles in a closed 40x16x20 room + 12 wall trian
 16 procedural 1024^2 RGBA8 texture sets, 66 materials, white environment, ray_depth 8) — the reference ships no
 Sponza asset, so this is the "Sponza-sized synthetic triangle set" BASELINE.json names.
 
-One step = one pass of the hot path over one batch = one full render of the 1000x1000 image: rt_render() through the
-C-ABI with the framebuffer resident in HBM (RT_FLAG_DEVICE_FB) + for N > 1 the RCCL gather of the float3
-framebuffer to rank 0. Scene upload and BVH build happen once before the timed region, like the reference's
+One step = one pass of the hot path over one batch = one full render of the 1000x1000 image: rt_render_rgb8() through
+the C-ABI (render + the film on the device, i.e. what run_raytracer leaves in the reference's Image) with the image
+resident in HBM (RT_FLAG_DEVICE_FB) + for N > 1 the RCCL gather of the rgb8 image to rank 0 (--film none: rt_render()
+and the float3 framebuffer instead). Scene upload and BVH build happen once before the timed region, like the reference's
 RaytracerStaticContext (raytracer.h:633) precedes its pixel loop.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the image is sharded in interleaved 8-row tiles
@@ -78,6 +79,7 @@ def main() -> None:
     ap.add_argument("--triangles", type=int, default=N_TRIANGLES)
     ap.add_argument("--tex-size", type=int, default=TEX_SIZE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--film", default="device", choices=["device", "none"], help="device: rt_render_rgb8 (film on the GPU, rgb8 gathered); none: rt_render (float3 gathered)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 flow on fewer GPUs (all ranks on GPU 0, gather staged through host)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     args = ap.parse_args()
@@ -121,14 +123,19 @@ def main() -> None:
     block = SHARD_ROWS * W
     sharding = importlib.import_module("raytracing-course-hw-public_amd.sharding")
     fb = torch.zeros(n_pix * 3, dtype=torch.float32, device=device)
+    film = args.film == "device"
+    img = torch.zeros(n_pix * 3, dtype=torch.uint8, device=device) if film else fb
     gather_device = device if args.backend == "nccl" else torch.device("cpu")
-    gather = sharding.FramebufferGather(n_pix, block, rank, world, gather_device)
+    gather = sharding.FramebufferGather(n_pix, block, rank, world, gather_device, dtype=img.dtype)
     my_pixels = sharding.shard_pixels(n_pix, block, rank, world)
 
     def step():
-        _, st = dev.run_raytracer(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr())
+        if film:
+            _, st = dev.run_raytracer_rgb8(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_rgb8=img.data_ptr())
+        else:
+            _, st = dev.run_raytracer(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr())
         # N > 1: RCCL gather of this rank's interleaved blocks to rank 0 over xGMI (no-op at N = 1)
-        gather.gather(fb if args.backend == "nccl" else fb.cpu())
+        gather.gather(img if args.backend == "nccl" else img.cpu())
         return st
 
     def sync():
@@ -237,7 +244,8 @@ def main() -> None:
                 "height": H,
                 "spp": spp,
                 "triangles": int(scene.n_triangles),
-                "sharding": f"interleaved {SHARD_ROWS}-row tiles over {world} GPU(s), RCCL gather of float3 framebuffer" if world > 1 else "single GPU",
+                "sharding": f"interleaved {SHARD_ROWS}-row tiles over {world} GPU(s), RCCL gather of the {'rgb8 image' if film else 'float3 framebuffer'}" if world > 1 else "single GPU",
+                "film": "device (rt_render_rgb8)" if film else "none (linear float3)",
             },
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

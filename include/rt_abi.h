@@ -53,7 +53,8 @@ enum {
     RT_ERR_OOM = 4,
     RT_ERR_IO = 5,
     RT_ERR_FORMAT = 6,
-    RT_ERR_COMM = 7
+    RT_ERR_COMM = 7,
+    RT_ERR_UNSUPPORTED = 8 /* a precondition of an optional fast path does not hold on this host; use the plain path */
 };
 
 /* RNG / transcendental policy of the sample loop.
@@ -189,6 +190,16 @@ int rt_bvh_info(rt_scene *scene, int which, uint32_t *n_nodes, uint32_t *n_objec
 
 /* Film (image.h:49-82): ACES -> gamma 1/2.2 -> x255 -> clamp -> round -> u8. Host function; n pixels. */
 void rt_tonemap_rgb8(const float *rgb, size_t n_pixels, uint8_t *out_rgb8);
+
+/* The same film on the device. rt_render_rgb8 = run_raytracer(scene, image) with the reference's own
+ * output type: Image::set_pixel tone-maps each finished pixel at once (image.h:40-42), so the image the reference
+ * holds after raytracer.h:629-674 is rgb8. Same parameters, sharding and flags as rt_render; `rgb8` receives
+ * width*height*3 bytes (a device pointer with RT_FLAG_DEVICE_FB; only this shard's pixels are written), byte-identical
+ * to rt_tonemap_rgb8 of the rt_render framebuffer. The gamma stage uses a threshold table derived from, and verified
+ * against, the host libm's powf when the first call is made; if that verification fails the call returns an error
+ * (no approximation is ever substituted). rt_film_rgb8 applies the device film to a caller-supplied host array. */
+int rt_render_rgb8(rt_scene *scene, const rt_params *params, uint8_t *rgb8, rt_stats *stats);
+int rt_film_rgb8(rt_scene *scene, const float *rgb, size_t n_pixels, uint8_t *out_rgb8);
 
 const char *rt_last_error(void);
 uint32_t rt_abi_version(void);

@@ -27,6 +27,11 @@ void rt_loaded_free(rt_loaded_scene *s);
  * main.cpp:40-41. */
 int rt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb8);
 
+/* The gamma + quantise stage of the film (image.h:61-82) as the device film uses it: thr[k] (k = 1..255) is the smallest
+ * ACES value whose level is >= k, thr[0] = 0; special = levels of {NaN, negative finite, -inf}. Built from the host
+ * libm's powf and verified against it; returns RT_OK only if the verification held (see host/film.cpp). */
+int rt_film_table(float thr[256], uint32_t special[3]);
+
 /* BVH::build(objs, pred) (bvh.h:368-393) on the host, without a GPU: the same builder rt_create uses (reference topology,
  * subtrees built in parallel). `subset` = original indices of the triangles that pass the predicate, in scene order.
  * Output as rt_bvh_info: 10 words per node in the reference's pre-order numbering + the object permutation. The node

@@ -157,6 +157,39 @@ class DeviceScene:
         _check(lib().rt_render(self._h, C.byref(p), fb.ctypes.data_as(C.c_void_p), C.byref(st)))
         return fb, st.as_dict()
 
+    def run_raytracer_rgb8(
+        self,
+        width: int,
+        height: int,
+        samples: int,
+        seed: int = 0,
+        shard_index: int = 0,
+        shard_count: int = 1,
+        shard_block: int = 0,
+        out: Optional[np.ndarray] = None,
+        device_rgb8: int = 0,
+        rng_mode: int = RT_RNG_DEVICE,
+    ):
+        """run_raytracer(scene, image) with the reference's own output type (image.h:40-42): the tone-mapped rgb8 image,
+        film applied on the device. Returns ((H,W,3) uint8 array or None with `device_rgb8`, stats dict)."""
+        p = RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block, 0)
+        st = RtStats()
+        if device_rgb8:
+            p.flags |= RT_FLAG_DEVICE_FB
+            _check(lib().rt_render_rgb8(self._h, C.byref(p), C.c_void_p(device_rgb8), C.byref(st)))
+            return None, st.as_dict()
+        img = out if out is not None else np.zeros((height, width, 3), dtype=np.uint8)
+        assert img.dtype == np.uint8 and img.flags["C_CONTIGUOUS"] and img.size == width * height * 3
+        _check(lib().rt_render_rgb8(self._h, C.byref(p), img.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return img, st.as_dict()
+
+    def film_rgb8(self, fb: np.ndarray) -> np.ndarray:
+        """The device film (image.h:49-82 on the GPU) applied to a host float array of shape (..., 3)."""
+        fb = np.ascontiguousarray(fb, dtype=np.float32)
+        out = np.zeros(fb.shape, dtype=np.uint8)
+        _check(lib().rt_film_rgb8(self._h, fptr(fb), fb.size // 3, u8ptr(out)))
+        return out
+
     def cast_rays(self, rays: np.ndarray):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
         n = rays.shape[0]
@@ -201,6 +234,14 @@ def tonemap(fb: np.ndarray) -> np.ndarray:
     out = np.zeros(fb.shape, dtype=np.uint8)
     lib().rt_tonemap_rgb8(fptr(fb), fb.size // 3, u8ptr(out))
     return out
+
+
+def film_table():
+    """(thr[256] float32, special[3] uint32): the verified gamma + quantise thresholds the device film searches."""
+    thr = np.zeros(256, dtype=np.float32)
+    special = np.zeros(3, dtype=np.uint32)
+    _check(lib().rt_film_table(fptr(thr), u32ptr(special)))
+    return thr, special
 
 
 def write_ppm(path: str, rgb8: np.ndarray) -> None:

@@ -27,6 +27,7 @@ ERROR_NAMES = {
     5: "RT_ERR_IO",
     6: "RT_ERR_FORMAT",
     7: "RT_ERR_COMM",
+    8: "RT_ERR_UNSUPPORTED",
 }
 
 c_float_p = C.POINTER(C.c_float)
@@ -129,6 +130,8 @@ ABI_PROTOTYPES = {
     "rt_light_pdf": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, c_float_p]),
     "rt_bvh_info": (C.c_int, [C.c_void_p, C.c_int, c_u32_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
     "rt_tonemap_rgb8": (None, [c_float_p, C.c_size_t, c_u8_p]),
+    "rt_render_rgb8": (C.c_int, [C.c_void_p, C.POINTER(RtParams), C.c_void_p, C.POINTER(RtStats)]),
+    "rt_film_rgb8": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_u8_p]),
     "rt_last_error": (C.c_char_p, []),
     "rt_abi_version": (C.c_uint32, []),
     "rt_device_count": (C.c_int, []),
@@ -140,6 +143,7 @@ HOST_PROTOTYPES = {
     "rt_write_ppm": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, c_u8_p]),
     "rt_png_decode_file": (C.c_int, [C.c_char_p, c_u32_p, c_u32_p, C.POINTER(c_u8_p)]),
     "rt_free": (None, [C.c_void_p]),
+    "rt_film_table": (C.c_int, [c_float_p, c_u32_p]),
     "rt_bvh_build_host": (C.c_int, [c_float_p, C.c_uint32, c_u32_p, C.c_uint32, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
 }
 

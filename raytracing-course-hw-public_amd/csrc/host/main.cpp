@@ -1,7 +1,7 @@
 // main.cpp — host driver behind the reference's CLI:  run.sh <scene.gltf> <W> <H> <SPP> <out.ppm>
 // Restates src/main.cpp:16-49: parse 5 positional arguments, load the scene, render, tone-map, write the PPM.
 // The only change of substance is line 37 of the reference: run_raytracer(scene, img) becomes
-// rt_create + rt_render through the C ABI (include/rt_abi.h); the film (image.h) is applied afterwards.
+// rt_create + rt_render_rgb8 through the C ABI (include/rt_abi.h): render and film (image.h) on the device.
 // Optional environment: RT_DEVICE (HIP ordinal, default 0), RT_RNG_MODE (device|reference), RT_SEED.
 #include <cstdio>
 #include <cstdlib>
@@ -47,15 +47,22 @@ int main(int argc, char **argv) {
     p.rng_mode = (mode && !std::strcmp(mode, "reference")) ? RT_RNG_REFERENCE : RT_RNG_DEVICE;
     const char *seed = std::getenv("RT_SEED");
     p.seed = seed ? std::strtoull(seed, nullptr, 0) : 0;
-    std::vector<float> fb((size_t)width * height * 3, 0.0f);
+    // Image::set_pixel tone-maps as pixels finish (image.h:40-42): the film runs on the device too, unless the host
+    // film is asked for (RT_FILM=host) or the device film declines (RT_ERR_UNSUPPORTED: libm failed its self-check)
+    std::vector<uint8_t> rgb8((size_t)width * height * 3, 0);
     rt_stats st{};
-    int rc = rt_render(scene, &p, fb.data(), &st);
+    const char *film = std::getenv("RT_FILM");
+    int rc = (film && !std::strcmp(film, "host")) ? RT_ERR_UNSUPPORTED : rt_render_rgb8(scene, &p, rgb8.data(), &st);
+    if (rc == RT_ERR_UNSUPPORTED) {
+        std::vector<float> fb((size_t)width * height * 3, 0.0f);
+        rc = rt_render(scene, &p, fb.data(), &st);
+        if (rc == RT_OK)
+            rt_tonemap_rgb8(fb.data(), (size_t)width * height, rgb8.data());
+    }
     rt_destroy(scene);
     rt_loaded_free(loaded);
     if (rc != RT_OK)
         return die("rt_render");
-    std::vector<uint8_t> rgb8(fb.size());
-    rt_tonemap_rgb8(fb.data(), (size_t)width * height, rgb8.data());
     if (rt_write_ppm(argv[5], width, height, rgb8.data()) != RT_OK)
         return die("write");
     if (std::getenv("RT_VERBOSE"))

@@ -18,6 +18,7 @@
 #include "bvh_build.h"
 #include "rt_device_types.h"
 #include "rt_error.h"
+#include "rt_film.h"
 #include "rt_kernels.h"
 
 namespace {
@@ -62,6 +63,46 @@ struct rt_scene {
     DevStats *d_stats = nullptr;
     float *d_fb = nullptr;
     size_t fb_capacity = 0; // floats
+    uint8_t *d_rgb8 = nullptr; // device film output (rt_render_rgb8 with a host destination, rt_film_rgb8)
+    size_t rgb8_capacity = 0;
+    rt::FilmTable *d_film_table = nullptr;
+
+    int ensure_fb(size_t fb_floats) {
+        if (fb_capacity >= fb_floats)
+            return RT_OK;
+        if (d_fb)
+            (void)hipFree(d_fb);
+        d_fb = nullptr;
+        fb_capacity = 0;
+        void *q = nullptr;
+        HIP_TRY(hipMalloc(&q, fb_floats * sizeof(float)));
+        d_fb = static_cast<float *>(q);
+        fb_capacity = fb_floats;
+        return RT_OK;
+    }
+    // device film prerequisites: the verified threshold table (host/film.cpp) and, optionally, an rgb8 staging buffer
+    int ensure_film(size_t rgb8_bytes) {
+        if (!d_film_table) {
+            rt::FilmTable t{};
+            if (!rt::film_table(t.thr, t.special))
+                return rt::fail(RT_ERR_UNSUPPORTED, "device film: the host libm's powf failed the monotonicity check; use rt_render + rt_tonemap_rgb8");
+            void *q = nullptr;
+            HIP_TRY(hipMalloc(&q, sizeof(t)));
+            d_film_table = static_cast<rt::FilmTable *>(q);
+            HIP_TRY(hipMemcpy(d_film_table, &t, sizeof(t), hipMemcpyHostToDevice));
+        }
+        if (rgb8_capacity < rgb8_bytes) {
+            if (d_rgb8)
+                (void)hipFree(d_rgb8);
+            d_rgb8 = nullptr;
+            rgb8_capacity = 0;
+            void *q = nullptr;
+            HIP_TRY(hipMalloc(&q, rgb8_bytes));
+            d_rgb8 = static_cast<uint8_t *>(q);
+            rgb8_capacity = rgb8_bytes;
+        }
+        return RT_OK;
+    }
     int num_cus = 0;
     int blocks_per_cu = 8; // upper bound on resident 256-thread blocks per CU; surplus blocks find the ticket exhausted
     // wavefront pipeline workspace (rt_wavefront.hip), sized for wf_paths_cap paths / wf_pixels_cap pixels per pass
@@ -123,6 +164,10 @@ struct rt_scene {
             (void)hipFree(p);
         if (d_fb)
             (void)hipFree(d_fb);
+        if (d_rgb8)
+            (void)hipFree(d_rgb8);
+        if (d_film_table)
+            (void)hipFree(d_film_table);
         if (ev0)
             (void)hipEventDestroy(ev0);
         if (ev1)
@@ -313,8 +358,9 @@ extern "C" int rt_create(const rt_scene_desc *desc, int device, rt_scene **out) 
 
 extern "C" void rt_destroy(rt_scene *scene) { delete scene; }
 
-extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stats *stats) {
-    if (!s || !p || !fb_rgb)
+// rt_render (fb_rgb: linear float3) and rt_render_rgb8 (rgb8_out: the tone-mapped image, film on the device)
+static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *rgb8_out, rt_stats *stats) {
+    if (!s || !p || (!fb_rgb && !rgb8_out))
         return rt::fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
     if (p->width == 0 || p->height == 0 || (uint64_t)p->width * p->height >= 0x7FFFFFFFull)
         return rt::fail(RT_ERR_INVALID_ARG, "Illegal image size" + std::to_string(p->width) + "x" + std::to_string(p->height)); // image.h:26
@@ -365,18 +411,18 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
     const bool device_fb = (p->flags & RT_FLAG_DEVICE_FB) != 0;
     const size_t fb_floats = (size_t)n_pix * 3;
     float *d_fb = fb_rgb;
-    if (!device_fb) {
-        if (s->fb_capacity < fb_floats) {
-            if (s->d_fb)
-                (void)hipFree(s->d_fb);
-            s->d_fb = nullptr;
-            s->fb_capacity = 0;
-            void *q = nullptr;
-            HIP_TRY(hipMalloc(&q, fb_floats * sizeof(float)));
-            s->d_fb = static_cast<float *>(q);
-            s->fb_capacity = fb_floats;
-        }
+    if (!device_fb || rgb8_out) { // the float framebuffer is internal unless the caller keeps it in HBM
+        int rc = s->ensure_fb(fb_floats);
+        if (rc != RT_OK)
+            return rc;
         d_fb = s->d_fb;
+    }
+    uint8_t *d_rgb8 = nullptr;
+    if (rgb8_out) {
+        int rc = s->ensure_film(device_fb ? 0 : fb_floats);
+        if (rc != RT_OK)
+            return rc;
+        d_rgb8 = device_fb ? rgb8_out : s->d_rgb8;
     }
     L.fb = d_fb;
     L.counter = s->d_counter;
@@ -391,6 +437,7 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
         blocks = 1;
     const bool wavefront = p->rng_mode == RT_RNG_DEVICE && !(p->flags & RT_FLAG_MEGAKERNEL);
     std::vector<hipEvent_t> extend_events; // (start, stop) per wf_extend launch
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (L.n_items > 0 && wavefront) {
         // ---- production path: wavefront pipeline over (pixel tile) x (sample range) passes, all stream-ordered
         // Paths per pass: the larger a pass, the smaller the share of each bounce launch's drain phase (measured on
@@ -448,7 +495,6 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
         W.sort_mode = sort_env ? (uint32_t)std::atoi(sort_env) : 1u;
         W.sort_temp_bytes = s->wf_sort_temp_bytes;
         W.stats = L.stats;
-        HIP_TRY(hipEventRecord(s->ev0, s->stream));
         for (uint64_t p0 = 0; p0 < local_pixels; p0 += tile_pixels) {
             W.first_pixel = (uint32_t)p0;
             W.pass_pixels = (uint32_t)std::min<uint64_t>(tile_pixels, local_pixels - p0);
@@ -460,25 +506,27 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
                                                   stats ? &extend_events : nullptr));
             }
         }
-        HIP_TRY(hipEventRecord(s->ev1, s->stream));
     } else if (L.n_items > 0) {
         // ---- persistent megakernel: reference-RNG parity mode, or RT_FLAG_MEGAKERNEL cross-check
-        HIP_TRY(hipEventRecord(s->ev0, s->stream));
         HIP_TRY(rt::launch_render(s->dev, L, counters, blocks, s->stream));
-        HIP_TRY(hipEventRecord(s->ev1, s->stream));
     }
+    if (rgb8_out && L.n_items > 0) // film on the device: this shard's pixels -> rgb8 (image.h:49-82)
+        HIP_TRY(rt::launch_film(d_fb, d_rgb8, n_pix, L.shard_index, L.shard_count, block, s->d_film_table, s->stream));
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     float ms = 0;
-    if (L.n_items > 0)
-        HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
 
-    if (!device_fb && L.n_items > 0) {
+    if (!device_fb && L.n_items > 0) { // copy back only this shard's blocks; other pixels of the destination stay untouched
+        const size_t elem = rgb8_out ? 1 : sizeof(float);
+        char *dst = rgb8_out ? reinterpret_cast<char *>(rgb8_out) : reinterpret_cast<char *>(fb_rgb);
+        const char *src = rgb8_out ? reinterpret_cast<const char *>(d_rgb8) : reinterpret_cast<const char *>(d_fb);
         if (L.shard_count == 1) {
-            HIP_TRY(hipMemcpy(fb_rgb, d_fb, fb_floats * sizeof(float), hipMemcpyDeviceToHost));
-        } else { // copy back only this shard's blocks; other pixels of fb_rgb stay untouched
+            HIP_TRY(hipMemcpy(dst, src, fb_floats * elem, hipMemcpyDeviceToHost));
+        } else {
             for (uint64_t b = L.shard_index; b < n_blocks; b += L.shard_count) {
                 uint64_t first = b * block, last = std::min<uint64_t>(first + block, n_pix);
-                HIP_TRY(hipMemcpy(fb_rgb + 3 * first, d_fb + 3 * first, (last - first) * 3 * sizeof(float), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(dst + 3 * first * elem, src + 3 * first * elem, (last - first) * 3 * elem, hipMemcpyDeviceToHost));
             }
         }
     }
@@ -515,6 +563,36 @@ extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stat
         }
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     }
+    return RT_OK;
+}
+
+extern "C" int rt_render(rt_scene *s, const rt_params *p, float *fb_rgb, rt_stats *stats) {
+    if (!fb_rgb)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
+    return render_impl(s, p, fb_rgb, nullptr, stats);
+}
+
+extern "C" int rt_render_rgb8(rt_scene *s, const rt_params *p, uint8_t *rgb8, rt_stats *stats) {
+    if (!rgb8)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_render_rgb8: null argument");
+    return render_impl(s, p, nullptr, rgb8, stats);
+}
+
+extern "C" int rt_film_rgb8(rt_scene *s, const float *rgb, size_t n_pixels, uint8_t *out_rgb8) {
+    if (!s || (n_pixels && (!rgb || !out_rgb8)) || n_pixels >= 0x7FFFFFFFull)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_film_rgb8: bad argument");
+    if (n_pixels == 0)
+        return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = s->ensure_fb(n_pixels * 3);
+    if (rc == RT_OK)
+        rc = s->ensure_film(n_pixels * 3);
+    if (rc != RT_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_fb, rgb, n_pixels * 3 * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(rt::launch_film(s->d_fb, s->d_rgb8, (uint32_t)n_pixels, 0, 1, (uint32_t)n_pixels, s->d_film_table, s->stream));
+    HIP_TRY(hipMemcpyAsync(out_rgb8, s->d_rgb8, n_pixels * 3, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     return RT_OK;
 }
 

@@ -1,4 +1,5 @@
-"""Image sharding across GPUs: interleaved pixel blocks + one gather of the float3 framebuffer.
+"""Image sharding across GPUs: interleaved pixel blocks + one gather of the framebuffer (linear float3,
+or rgb8 when the film ran on the device: rt_render_rgb8, a 4x smaller message).
 
 The reference self-schedules disjoint 256-pixel spans over CPU threads (raytracer.h:640-659); pixels are independent
 given the read-only scene. Here the scene is replicated per GPU and the image is split into blocks of
@@ -31,14 +32,14 @@ class FramebufferGather:
     """Reusable buffers + the gather itself. `fb` is the rank's full-size flat framebuffer (n_pix*3 floats) in which
     only this rank's blocks are valid (that is what rt_render writes with shard_count = world)."""
 
-    def __init__(self, n_pix: int, block: int, rank: int, world: int, device: torch.device):
+    def __init__(self, n_pix: int, block: int, rank: int, world: int, device: torch.device, dtype: torch.dtype = torch.float32):
         self.n_pix, self.block, self.rank, self.world = n_pix, block, rank, world
         self.nb = n_blocks(n_pix, block)
         self.max_blocks = (self.nb + world - 1) // world
-        self.padded = torch.zeros(self.nb * block * 3, dtype=torch.float32, device=device)
-        self.slab = torch.zeros(self.max_blocks * block * 3, dtype=torch.float32, device=device)
+        self.padded = torch.zeros(self.nb * block * 3, dtype=dtype, device=device)
+        self.slab = torch.zeros(self.max_blocks * block * 3, dtype=dtype, device=device)
         self.gathered = [torch.empty_like(self.slab) for _ in range(world)] if (world > 1 and rank == 0) else None
-        self.full = torch.zeros(self.nb * block * 3, dtype=torch.float32, device=device) if rank == 0 else None
+        self.full = torch.zeros(self.nb * block * 3, dtype=dtype, device=device) if rank == 0 else None
         import os
 
         self.use_all_gather = os.environ.get("RT_GATHER", "gather") == "allgather"
@@ -53,7 +54,7 @@ class FramebufferGather:
         self.slab[: mine.numel()] = mine.reshape(-1)
         if self.use_all_gather:  # RT_GATHER=allgather: same bytes per link on a ring, every rank ends up with the slabs
             if self.all_slabs is None:
-                self.all_slabs = torch.empty(self.world * self.slab.numel(), dtype=torch.float32, device=self.slab.device)
+                self.all_slabs = torch.empty(self.world * self.slab.numel(), dtype=self.slab.dtype, device=self.slab.device)
             dist.all_gather_into_tensor(self.all_slabs, self.slab)
             if self.rank != 0:
                 return None

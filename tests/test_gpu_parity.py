@@ -351,3 +351,78 @@ def test_reference_rng_mode_close_to_reference_binary_golden(gpu, sg, oracle, tm
         differing = int((img != ref).any(axis=2).sum())
         assert differing <= 0.02 * 64 * 48, f"{name}: {differing} of {64 * 48} pixels differ from the reference binary's PPM"
         dev.close()
+
+
+# ------------------------------------------------------------------------------------------------ device film (8f-3)
+def _film_edge_values():
+    rng = np.random.default_rng(12)
+    thr, _ = None, None
+    vals = [rng.uniform(0, 4, 200000), rng.uniform(0, 0.02, 20000), 10.0 ** rng.uniform(-44, 38, 50000), -(10.0 ** rng.uniform(-44, 38, 2000)),
+            [0.0, -0.0, 1.0, 0.18, 1e6, 3.4e38, np.inf, -np.inf, np.nan, 1e-45, -1e-45, -0.012345679, -0.0123456]]
+    with np.errstate(over="ignore"):
+        return np.concatenate([np.asarray(v, dtype=np.float64) for v in vals]).astype(np.float32)
+
+
+def test_device_film_matches_oracle_film(pairs, gpu, oracle):
+    """rt_film_rgb8 (ACES on the device + verified threshold table) == the oracle's film (image.h:49-82 with libm powf),
+    byte for byte: random radiances, all exponents, negatives, NaN, infinities, and every float within 3 ulps of every
+    one of the 255 level thresholds mapped back through the ACES curve's neighbourhood."""
+    dev, _, _ = pairs["room_plain"]
+    x = _film_edge_values()
+    # radiances whose ACES value lands next to a threshold: bisect x for each threshold, then take its float neighbours
+    thr, special = gpu.film_table()
+    a, b, c, d, e = (np.float32(v) for v in (2.51, 0.03, 2.43, 0.59, 0.14))
+    lo, hi = np.zeros(256, dtype=np.float32), np.full(256, 64.0, dtype=np.float32)
+    for _ in range(60):
+        mid = ((lo.astype(np.float64) + hi) / 2).astype(np.float32)
+        y = (mid * (a * mid + b)) / (mid * (c * mid + d) + e)
+        below = y < thr
+        lo, hi = np.where(below, mid, lo), np.where(below, hi, mid)
+    near = (hi.view(np.uint32)[:, None].astype(np.int64) + np.arange(-6, 7)[None, :]).clip(0, 0x7F7FFFFF).astype(np.uint32).view(np.float32).ravel()
+    x = np.concatenate([x, near])
+    x = np.concatenate([x, np.zeros((-x.size) % 3, dtype=np.float32)]).reshape(-1, 1, 3)
+    got = dev.film_rgb8(x)
+    want = oracle.tonemap(x)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {got.size} values differ"
+    assert np.array_equal(got, gpu.tonemap(x))  # and the product's own host film
+    assert got.min() == 0 and got.max() == 255
+
+
+@pytest.mark.parametrize("name", ["room_textured", "boxes"])
+def test_render_rgb8_equals_film_of_float_render(pairs, gpu, oracle, name):
+    """rt_render_rgb8 == oracle film of the oracle framebuffer (hence == the PPM bytes the CPU path would write),
+    on one GPU and as the union of shards; pixels of other shards are not touched."""
+    dev, orc, _ = pairs[name]
+    W, H, SPP = 64, 48, 4
+    ofb, _ = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=21)
+    want = oracle.tonemap(ofb)
+    img, st = dev.run_raytracer_rgb8(W, H, SPP, seed=21)
+    assert np.array_equal(img, want)
+    assert st["samples"] == W * H * SPP
+    for G in (2, 5):
+        acc = np.full((H, W, 3), 77, dtype=np.uint8)
+        for r in range(G):
+            before = acc.copy()
+            dev.run_raytracer_rgb8(W, H, SPP, seed=21, shard_index=r, shard_count=G, shard_block=256, out=acc)
+            mine = np.zeros(W * H, dtype=bool)
+            for b0 in range(r * 256, W * H, G * 256):
+                mine[b0 : b0 + 256] = True
+            assert np.array_equal(acc.reshape(-1, 3)[~mine], before.reshape(-1, 3)[~mine])
+        assert np.array_equal(acc, want), f"G={G}"
+    # reference-RNG mode through the megakernel takes the same film
+    rfb, _ = dev.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE)
+    rimg, _ = dev.run_raytracer_rgb8(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE)
+    assert np.array_equal(rimg, oracle.tonemap(rfb))
+
+
+def test_render_rgb8_device_destination(pairs, gpu, oracle):
+    """RT_FLAG_DEVICE_FB with rt_render_rgb8: the image stays in HBM (what the multi-GPU gather consumes)."""
+    import torch
+
+    dev, orc, _ = pairs["room_plain"]
+    W, H, SPP = 40, 24, 3
+    t = torch.full((H * W * 3,), 9, dtype=torch.uint8, device="cuda")
+    dev.run_raytracer_rgb8(W, H, SPP, seed=2, device_rgb8=t.data_ptr())
+    torch.cuda.synchronize()
+    ofb, _ = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=2)
+    assert np.array_equal(t.cpu().numpy().reshape(H, W, 3), oracle.tonemap(ofb))

@@ -123,6 +123,27 @@ def test_tonemap_matches_oracle_film(rt, oracle):
     assert a.min() == 0 and a.max() == 255
 
 
+def test_film_threshold_table_reproduces_the_host_film(rt, oracle):
+    """The device film's gamma stage (rt_film_table: 255 thresholds over the ACES value, built from libm powf) gives the
+    same level as the host film and the oracle film for random radiances over all exponents; numpy float32 ACES is the
+    same five IEEE operations."""
+    thr, special = rt.film_table()
+    assert thr[0] == 0 and np.all(np.diff(thr) > 0) and thr[255] < 1.0
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(0, 4, 600000), 10.0 ** rng.uniform(-44, 38, 100000), [0.0, 1e-45, 3e38, np.inf, 0.18]]).astype(np.float32)
+    x = x[: (x.size // 3) * 3]
+    a, b, c, d, e = (np.float32(v) for v in (2.51, 0.03, 2.43, 0.59, 0.14))
+    with np.errstate(all="ignore"):
+        y = (x * (a * x + b)) / (x * (c * x + d) + e)
+    lvl = np.where(np.isnan(y), special[0], np.searchsorted(thr, y, side="right") - 1).astype(np.uint8)
+    want = oracle.tonemap(x.reshape(-1, 1, 3)).reshape(-1)
+    assert np.array_equal(lvl, want)
+    assert np.array_equal(rt.tonemap(x.reshape(-1, 1, 3)).reshape(-1), want)
+    neg = oracle.tonemap(np.array([[[-0.001, -np.inf, np.nan]]], dtype=np.float32)).reshape(-1)
+    # ACES of -0.001 is negative finite, of -inf and NaN is NaN: the documented specials
+    assert int(neg[0]) == int(special[1]) and int(neg[1]) == int(special[0]) and int(neg[2]) == int(special[0])
+
+
 def test_ppm_roundtrip_and_directory_creation(rt, oracle, tmp_path):
     img = np.random.default_rng(4).integers(0, 256, size=(7, 5, 3), dtype=np.uint8)
     path = tmp_path / "deep" / "er" / "o.ppm"  # main.cpp:41 create_directories

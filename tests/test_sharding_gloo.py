@@ -35,8 +35,13 @@ def _worker(rank, world, port, out_path, mode):
     g = sharding.FramebufferGather(n_pix, BLOCK, rank, world, torch.device("cpu"))
     full = g.gather(torch.from_numpy(fb.reshape(-1)))
     assert sharding.shard_pixels(n_pix, BLOCK, rank, world) == int((fb.reshape(-1, 3) != 0).any(axis=1).sum()) or True
+    # the rgb8 flow bench.py runs by default (film applied per rank, uint8 slabs gathered: a 4x smaller message)
+    img = oracle.tonemap(fb)
+    g8 = sharding.FramebufferGather(n_pix, BLOCK, rank, world, torch.device("cpu"), dtype=torch.uint8)
+    full8 = g8.gather(torch.from_numpy(img.reshape(-1)))
     if rank == 0:
         np.save(out_path, full.numpy().reshape(H, W, 3))
+        np.save(out_path + ".rgb8.npy", full8.numpy().reshape(H, W, 3))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,6 +55,7 @@ def test_gloo_sharded_render_equals_single_process(world, mode, tmp_path, rt, or
     sc = rt.scenegen.boxes_scene(n_boxes=6, seed=31, n_lights=2)
     ref, _ = oracle.OracleScene(sc).run_raytracer(W, H, SPP, seed=77)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(np.load(out + ".rgb8.npy"), oracle.tonemap(ref))
 
 
 def test_shard_bookkeeping(rt):
