@@ -295,6 +295,22 @@ template <int LDS_DEPTH> struct StackMemT {
             loc = ov_loc[sp - LDS_DEPTH];
         }
     }
+    // pop() inside straight-line wave code: every lane reads some valid LDS slot (sp may be negative or stale on lanes
+    // that do not `want` the frame), only wanting lanes look at the overflow part
+    DEV void pop_masked(int sp, bool want, uint32_t &ref, float &d, float &loc) {
+        const uint32_t slot = (uint32_t)sp < (uint32_t)LDS_DEPTH ? (uint32_t)sp : (uint32_t)(LDS_DEPTH - 1);
+        ref = lds[(0 * LDS_DEPTH + slot) * 256];
+        d = __uint_as_float(lds[(1 * LDS_DEPTH + slot) * 256]);
+        loc = __uint_as_float(lds[(2 * LDS_DEPTH + slot) * 256]);
+        // keep the LDS reads where they are: sunk into the branch below they would merge with the scratch loads into
+        // generic flat_loads of a selected pointer
+        asm volatile("" : "+v"(ref), "+v"(d), "+v"(loc));
+        if (want && sp >= LDS_DEPTH) {
+            ref = ov_ref[sp - LDS_DEPTH];
+            d = ov_d[sp - LDS_DEPTH];
+            loc = ov_loc[sp - LDS_DEPTH];
+        }
+    }
     // light-pdf traversal only needs child refs (bvh.h:237-260 has no ordering / pruning)
     DEV void push_ref(int sp, uint32_t ref) {
         if (sp < LDS_DEPTH)
@@ -508,6 +524,52 @@ template <bool STATS, class STK> DEV void trav_step_core(Trav &T, const DevBvh &
 template <bool STATS, class STK> DEV void trav_step(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
     trav_step_core<STATS>(T, bvh, stk, min_dst, st);
     trav_pop(T, stk);
+}
+
+// The same two operations for the wavefront kernel's hot loop, written so that a wave runs one straight-line sequence
+// (selects instead of per-lane branches: no exec-mask nesting and no register copies at control-flow joins).
+//   trav_step_inner_fast : trav_step_core for lanes the caller knows to be on an inner node with T.fast
+//   trav_pop_wave        : trav_pop for every lane in T_POP at once; lanes leave the loop as a wave
+template <bool STATS, class STK> DEV void trav_step_inner_fast(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
+    const float4 *p = reinterpret_cast<const float4 *>(bvh.nodes + T.cur);
+    const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+    const float2 r3 = *reinterpret_cast<const float2 *>(p + 3);
+    st.node();
+    st.box(2);
+    const uint32_t left = __float_as_uint(r3.x), right = __float_as_uint(r3.y);
+    float dl, dr;
+    const bool hl = box_hit_fast(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), T.o, T.d, T.r, min_dst, dl);
+    const bool hr = box_hit_fast(mk(r1.z, r1.w, r2.x), mk(r2.y, r2.z, r2.w), T.o, T.d, T.r, min_dst, dr);
+    const bool both = hl & hr;
+    const bool swap = dl > dr; // bvh.h:216 (ties keep left first)
+    if (both & (T.sp > 0))
+        stk.push(T.sp - 1, T.top_ref, T.top_d, T.top_loc); // spill the previous top
+    T.top_ref = both ? (swap ? left : right) : T.top_ref;
+    T.top_d = both ? (swap ? dl : dr) : T.top_d;
+    T.top_loc = both ? T.t_loc : T.top_loc;
+    T.sp += both ? 1 : 0;
+    T.t_loc = both ? RT_NAN : T.t_loc;
+    T.cur = both ? (swap ? right : left) : (hl ? left : (hr ? right : T_POP));
+}
+template <class STK> DEV void trav_pop_wave(Trav &T, STK &stk) {
+    while (__ballot(T.cur == T_POP) != 0ull) {
+        DIAG(7, 1);
+        const bool pop = T.cur == T_POP;
+        const bool go = pop & (T.sp != 0);
+        const int nsp = T.sp - 1;
+        const bool refill = go & (nsp > 0);
+        uint32_t n_ref;
+        float n_d, n_loc;
+        stk.pop_masked(nsp - 1, refill, n_ref, n_d, n_loc);
+        const float t_near = T.t_loc;
+        const bool visit = !(t_near <= T.top_d); // !has || t_near > d_far (bvh.h:221)
+        T.cur = pop ? (go ? (visit ? T.top_ref : T_POP) : T_DONE) : T.cur;
+        T.t_loc = go ? fminf(T.top_loc, t_near) : t_near;
+        T.sp = go ? nsp : T.sp;
+        T.top_ref = refill ? n_ref : T.top_ref;
+        T.top_d = refill ? n_d : T.top_d;
+        T.top_loc = refill ? n_loc : T.top_loc;
+    }
 }
 
 // bvh_mix_dist::pdf (raytracer.h:363-375) = BVH::foreach_intersection (bvh.h:237-260) over the light BVH summing

@@ -47,6 +47,9 @@ using ShadeStack = StackMemT<RT_SHADE_LDS_DEPTH>;
 #ifndef RT_EXT_CHUNK
 #define RT_EXT_CHUNK 128u /* queue positions a wave takes per ticket atomic */
 #endif
+#ifndef RT_EXT_LEAN
+#define RT_EXT_LEAN 1 /* straight-line node step + wave-uniform unwind loop (see rt_device_lib.h) */
+#endif
 #ifndef RT_EXT_POP_LOOP
 #define RT_EXT_POP_LOOP 1 /* 1: unwind with a loop inside the step (measured faster); 0: one frame per pass */
 #endif
@@ -176,7 +179,9 @@ DEV void leaf_batch(Trav &T, const DevBvh &bvh, ExtStack &stk, bool at_leaf, uin
             T.t_loc = fminf(T.t_loc, t);
         }
         T.cur = T_POP;
-#if RT_EXT_POP_LOOP
+#if RT_EXT_LEAN
+        // unwound by the caller's trav_pop_wave
+#elif RT_EXT_POP_LOOP
         trav_pop(T, stk);
 #else
         trav_pop_once(T, stk);
@@ -267,7 +272,25 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
         }
         if (sm == 0ull || __popcll(lm) >= RT_EXT_LEAF_MIN) {
             leaf_batch<STATS>(T, S.scene, stk, at_leaf, s_owner, s_min, s_bc, st);
-        } else if (stepper) {
+        }
+#if RT_EXT_LEAN
+        else {
+            // the common wave: every stepping lane is on an inner node with the fast-division guarantees -> straight-line
+            // node step; a wave with a big-leaf walker or a guarded ray takes the general step
+            const bool plain = (T.cur & RT_LEAF_FLAG) == 0 && T.fast;
+            if (__ballot(stepper && !plain) == 0ull) {
+                if (stepper) {
+                    DIAG(18, 1);
+                    DIAG_LANES(19);
+                    trav_step_inner_fast<STATS>(T, S.scene, stk, EPS, st);
+                }
+            } else if (stepper) {
+                trav_step_core<STATS>(T, S.scene, stk, EPS, st);
+            }
+        }
+        trav_pop_wave(T, stk);
+#else
+        else if (stepper) {
             DIAG(18, 1);
             DIAG_LANES(19);
             trav_step_core<STATS>(T, S.scene, stk, EPS, st);
@@ -278,6 +301,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
                 trav_pop_once(T, stk);
 #endif
         }
+#endif
         if (active && T.cur == T_DONE)
             *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
     }
