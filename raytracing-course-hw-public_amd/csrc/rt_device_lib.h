@@ -145,20 +145,22 @@ template <> struct Rng<RT_RNG_REFERENCE> {
 template <class R> DEV float uniform_real(R &r, float a, float b) { return r.canonical() * (b - a) + a; }
 
 // ---------------------------------------------------------------------------------------------- primitives
-// Exact quotient a/d from a precomputed r = RN(1/d): two FMA correction steps (Markstein: with r the correctly
-// rounded reciprocal and a faithful q, RN(q + (a - d*q)*r) = RN(a/d); the first step makes q faithful). 5 VALU ops
-// instead of the ~11-op IEEE division expansion (v_div_scale/v_rcp/.../v_div_fixup). The residual a - d*q must be
-// exactly representable and nothing may overflow/underflow; that is guaranteed per RAY and per SCENE, not per box:
+// Exact quotient a/d from a precomputed r = RN(1/d): q0 = RN(a*r), one FMA residual e = a - d*q0 and one FMA correction
+// q1 = RN(q0 + e*r) = RN(a/d). 3 VALU ops instead of the ~11-op IEEE division expansion (v_div_scale / v_rcp / ... /
+// v_div_fixup). Why one correction suffices although q0 may be off by 1.5 ulp (Markstein's theorem wants a faithful
+// q0): the value rounded last is Q + (Q - q0)*eps with |eps| <= 2^-24, i.e. within ~3*2^-24 ulp of Q = a/d, and a
+// quotient of two 24-bit significands comes that close to a rounding boundary only for the finitely many pairs with
+// |A*2^k - B*m| <= 16 — all 93 million of which tools/proofs/div_one_step.c enumerates and checks against IEEE division
+// (run by tests/test_host_and_abi.py). The residual must be exactly representable and nothing may overflow/underflow;
+// that is guaranteed per RAY and per SCENE, not per box:
 //   * every direction component has |d_i| in [2^-40, 2^40]                                   (trav_init)
 //   * every origin component and every box coordinate is 0 or has magnitude in [2^-37, 2^40] (trav_init, host)
 // so a = box - o is 0 or a multiple of 2^-60 with |a| <= 2^41, hence q = 0 or 2^-100 <= |q| <= 2^81, all normal.
 // Rays (or scenes) outside these bounds take the reference IEEE division instead.
 DEV float div_exact_fast(float a, float d, float r) {
-    float q0 = a * r;
-    float e0 = __builtin_fmaf(-d, q0, a);
-    float q1 = __builtin_fmaf(e0, r, q0);
-    float e1 = __builtin_fmaf(-d, q1, a);
-    return __builtin_fmaf(e1, r, q1);
+    const float q0 = a * r;
+    const float e0 = __builtin_fmaf(-d, q0, a);
+    return __builtin_fmaf(e0, r, q0);
 }
 constexpr float RANGE_LO = 9.094947017729282e-13f;  // 2^-40
 constexpr float RANGE_HI = 1099511627776.0f;        // 2^40
@@ -414,24 +416,6 @@ DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
 // Unwind deferred siblings after a leaf or a double miss: the far child of the newest frame is visited iff the near
 // subtree found nothing or found t > d_far (bvh.h:221); either way the near result is merged into the enclosing
 // subtree's local best. Ends in T_DONE when the stack is empty.
-// One frame of trav_pop for a lane in state T_POP: afterwards T.cur is the far child (visit it), T_DONE (stack empty)
-// or still T_POP (sibling pruned: pop again later). Lets a wave unwind without a data-dependent inner loop.
-template <class STK> DEV void trav_pop_once(Trav &T, STK &stk) {
-    if (T.sp == 0) {
-        T.cur = T_DONE;
-        return;
-    }
-    --T.sp;
-    const uint32_t ref = T.top_ref;
-    const float dfar = T.top_d, saved = T.top_loc;
-    if (T.sp > 0)
-        stk.pop(T.sp - 1, T.top_ref, T.top_d, T.top_loc);
-    const float t_near = T.t_loc;
-    T.t_loc = fminf(saved, t_near);
-    if (!(t_near <= dfar)) // !has || t_near > d_far (bvh.h:221)
-        T.cur = ref;
-}
-
 template <class STK> DEV void trav_pop(Trav &T, STK &stk) {
     while (T.cur == T_POP) {
         DIAG(7, 1);
@@ -453,7 +437,7 @@ template <class STK> DEV void trav_pop(Trav &T, STK &stk) {
 }
 
 // One record: an inner node (two child boxes) or one triangle of a big leaf. Leaves T.cur == T_POP when the lane has to
-// unwind; the caller chooses how (trav_pop: loop until resolved; trav_pop_once: one frame now, the rest later).
+// unwind; the caller chooses how (trav_pop: per-lane loop; trav_pop_wave: all lanes of the wave together).
 template <bool STATS, class STK> DEV void trav_step_core(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
     const bool leaf = (T.cur & RT_LEAF_FLAG) != 0;
     const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (T.cur & RT_LEAF_BEGIN_MASK)) : reinterpret_cast<const float4 *>(bvh.nodes + T.cur);

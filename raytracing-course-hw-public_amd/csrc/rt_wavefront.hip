@@ -47,12 +47,6 @@ using ShadeStack = StackMemT<RT_SHADE_LDS_DEPTH>;
 #ifndef RT_EXT_CHUNK
 #define RT_EXT_CHUNK 128u /* queue positions a wave takes per ticket atomic */
 #endif
-#ifndef RT_EXT_LEAN
-#define RT_EXT_LEAN 1 /* straight-line node step + wave-uniform unwind loop (see rt_device_lib.h) */
-#endif
-#ifndef RT_EXT_POP_LOOP
-#define RT_EXT_POP_LOOP 1 /* 1: unwind with a loop inside the step (measured faster); 0: one frame per pass */
-#endif
 #ifndef RT_EXT_REFILL_MIN
 #define RT_EXT_REFILL_MIN 24 /* refill a wave's idle lanes once this many have finished (a refill stalls the wave on the ray loads) */
 #endif
@@ -117,7 +111,7 @@ template <bool STATS> __global__ __launch_bounds__(256) void wf_generate(const D
 // This removes the inner-node / triangle divergence of a one-record-per-lane step (about 58 % / 42 % of the lanes) and
 // packs the triangle tests: a wave does ~45 node tests or ~60 triangle tests per pass instead of ~32 + ~24.
 template <bool STATS>
-DEV void leaf_batch(Trav &T, const DevBvh &bvh, ExtStack &stk, bool at_leaf, uint16_t *s_owner, unsigned long long *s_min, float2 *s_bc, LaneStats<STATS> &st) {
+DEV void leaf_batch(Trav &T, const DevBvh &bvh, bool at_leaf, uint16_t *s_owner, unsigned long long *s_min, float2 *s_bc, LaneStats<STATS> &st) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = at_leaf ? RT_LEAF_CNT(T.cur) : 0u;
     uint32_t off = 0, total = 0;
@@ -178,14 +172,7 @@ DEV void leaf_batch(Trav &T, const DevBvh &bvh, ExtStack &stk, bool at_leaf, uin
             }
             T.t_loc = fminf(T.t_loc, t);
         }
-        T.cur = T_POP;
-#if RT_EXT_LEAN
-        // unwound by the caller's trav_pop_wave
-#elif RT_EXT_POP_LOOP
-        trav_pop(T, stk);
-#else
-        trav_pop_once(T, stk);
-#endif
+        T.cur = T_POP; // unwound by the caller's trav_pop_wave
     }
 }
 
@@ -247,34 +234,18 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
             q_lo += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
         }
         DIAG(12, 1);
-#if !RT_EXT_POP_LOOP
-        if (T.cur == T_POP) { // unwinding continues one frame per pass: no data-dependent loop inside the wave
-            trav_pop_once(T, stk);
-            if (T.cur == T_DONE)
-                *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
-        }
-        const bool popping = T.cur == T_POP;
-#else
-        constexpr bool popping = false;
-#endif
         const bool active = T.cur != T_DONE;
-        const bool at_leaf = active && !popping && (T.cur & RT_LEAF_FLAG) != 0 && RT_LEAF_CNT(T.cur) != 0;
-        const bool stepper = active && !popping && !at_leaf; // inner node, or a big leaf walked triangle by triangle
+        const bool at_leaf = active && (T.cur & RT_LEAF_FLAG) != 0 && RT_LEAF_CNT(T.cur) != 0;
+        const bool stepper = active && !at_leaf; // inner node, or a big leaf walked triangle by triangle
         const unsigned long long lm = __ballot(at_leaf), sm = __ballot(stepper);
         if ((lm | sm) == 0ull) {
-#if !RT_EXT_POP_LOOP
-            if (__ballot(popping) != 0ull)
-                continue; // only unwinding lanes left: next pass pops again
-#endif
             if (exhausted)
                 break;
             continue;
         }
         if (sm == 0ull || __popcll(lm) >= RT_EXT_LEAF_MIN) {
-            leaf_batch<STATS>(T, S.scene, stk, at_leaf, s_owner, s_min, s_bc, st);
-        }
-#if RT_EXT_LEAN
-        else {
+            leaf_batch<STATS>(T, S.scene, at_leaf, s_owner, s_min, s_bc, st);
+        } else {
             // the common wave: every stepping lane is on an inner node with the fast-division guarantees -> straight-line
             // node step; a wave with a big-leaf walker or a guarded ray takes the general step
             const bool plain = (T.cur & RT_LEAF_FLAG) == 0 && T.fast;
@@ -288,20 +259,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
                 trav_step_core<STATS>(T, S.scene, stk, EPS, st);
             }
         }
-        trav_pop_wave(T, stk);
-#else
-        else if (stepper) {
-            DIAG(18, 1);
-            DIAG_LANES(19);
-            trav_step_core<STATS>(T, S.scene, stk, EPS, st);
-#if RT_EXT_POP_LOOP
-            trav_pop(T, stk);
-#else
-            if (T.cur == T_POP)
-                trav_pop_once(T, stk);
-#endif
-        }
-#endif
+        trav_pop_wave(T, stk); // unwind after a leaf batch or a node step, all lanes of the wave together
         if (active && T.cur == T_DONE)
             *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
     }

@@ -113,6 +113,19 @@ def test_shared_sincos_is_within_half_ulp_plus_epsilon(oracle):
     assert np.all(s * s + c * c < 1.0000003)
 
 
+def test_one_step_exact_division_hard_cases(tmp_path):
+    """The slab test's 3-op exact division (div_exact_fast: a*r, one FMA residual, one FMA correction) equals IEEE
+    division on every significand pair that comes close enough to a rounding boundary to be at risk (exhaustive
+    enumeration, tools/proofs/div_one_step.c) — the argument that lets the HIP path drop the second correction."""
+    import subprocess
+
+    exe = str(tmp_path / "div_one_step")
+    subprocess.check_call(["gcc", "-O2", os.path.join(ROOT, "tools", "proofs", "div_one_step.c"), "-o", exe, "-lm"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert ", failures 0 " in r.stdout and "random failures 0" in r.stdout
+
+
 # ------------------------------------------------------------------------------------------------ film / PPM / PNG
 def test_tonemap_matches_oracle_film(rt, oracle):
     rng = np.random.default_rng(3)
