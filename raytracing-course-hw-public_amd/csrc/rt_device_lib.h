@@ -399,14 +399,18 @@ struct Trav {
     uint32_t top_ref;
     float top_d, top_loc;
 };
+// The per-ray half of div_exact_fast's preconditions (the per-scene half is DevBvh::fast_ok, checked by the host)
+DEV bool ray_fast_ok(const DevBvh &bvh, V3 o, V3 d) {
+    const float lo = fminf(fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    const float hi = fmaxf(fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    return (bvh.fast_ok != 0u) & (d.x == d.x) & (d.y == d.y) & (d.z == d.z) & (lo >= RANGE_LO) & (hi <= RANGE_HI) & coord_in_fast_range(o.x) &
+           coord_in_fast_range(o.y) & coord_in_fast_range(o.z);
+}
 DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
     T.o = o;
     T.d = d;
     T.r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    float lo = fminf(fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
-    float hi = fmaxf(fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
-    T.fast = (bvh.fast_ok != 0u) & (d.x == d.x) & (d.y == d.y) & (d.z == d.z) & (lo >= RANGE_LO) & (hi <= RANGE_HI) & coord_in_fast_range(o.x) &
-             coord_in_fast_range(o.y) & coord_in_fast_range(o.z);
+    T.fast = ray_fast_ok(bvh, o, d);
     T.cur = (bvh.root == RT_NONE || bvh.n_tris == 0) ? T_DONE : bvh.root;
     T.sp = 0;
     T.t_loc = RT_NAN;
@@ -565,6 +569,8 @@ template <bool STATS, class STK> DEV float lights_pdf(const DevScene &S, V3 x, V
     if (bvh.root != RT_NONE && bvh.n_tris != 0) {
         uint32_t cur = bvh.root;
         int sp = 0;
+        const bool fast = ray_fast_ok(bvh, x, d); // same exact-quotient shortcut as the closest-hit traversal
+        const V3 r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         while (cur != T_DONE) {
             const bool leaf = (cur & RT_LEAF_FLAG) != 0;
             const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (cur & RT_LEAF_BEGIN_MASK)) : reinterpret_cast<const float4 *>(bvh.nodes + cur);
@@ -575,8 +581,14 @@ template <bool STATS, class STK> DEV float lights_pdf(const DevScene &S, V3 x, V
                 st.lbox(2);
                 const uint32_t left = __float_as_uint(r3.x), right = __float_as_uint(r3.y);
                 float dl, dr;
-                bool hl = box_hit_exact(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), x, d, EPS, dl);
-                bool hr = box_hit_exact(mk(r1.z, r1.w, r2.x), mk(r2.y, r2.z, r2.w), x, d, EPS, dr);
+                bool hl, hr;
+                if (fast) {
+                    hl = box_hit_fast(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), x, d, r, EPS, dl);
+                    hr = box_hit_fast(mk(r1.z, r1.w, r2.x), mk(r2.y, r2.z, r2.w), x, d, r, EPS, dr);
+                } else {
+                    hl = box_hit_exact(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), x, d, EPS, dl);
+                    hr = box_hit_exact(mk(r1.z, r1.w, r2.x), mk(r2.y, r2.z, r2.w), x, d, EPS, dr);
+                }
                 if (hl & hr) {
                     stk.push_ref(sp++, right);
                     cur = left;
