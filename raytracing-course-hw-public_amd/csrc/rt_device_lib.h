@@ -647,7 +647,13 @@ DEV C4 tex_sample(const DevScene &S, int32_t tex, int dflt, float u, float v, bo
             return C4{1, 1, 1, 1}; // WHITE_TEXTURE geometry.h:601
         return C4{0.5f, 0.5f, 1, 0}; // NORMAL_UP geometry.h:602
     }
-    const DevTexture T = S.textures[tex];
+    DevTexture T;
+    {
+        const uint4 *tp = reinterpret_cast<const uint4 *>(S.textures + tex);
+        const uint4 t0 = tp[0], t1 = tp[1];
+        T.width = t0.x, T.height = t0.y, T.offset = t0.z, T.count = t0.w;
+        T.stride = t1.x, T.tiles_x = t1.y, T.tw_log = t1.z, T.th_log = t1.w;
+    }
     if (T.count == 1) { // 1x1 fast path returns the texel WITHOUT gamma (geometry.h:548-550)
         uint32_t p = S.texels[T.offset];
         return C4{s_lin[p & 255u], s_lin[(p >> 8) & 255u], s_lin[(p >> 16) & 255u], s_lin[p >> 24]};
@@ -659,18 +665,26 @@ DEV C4 tex_sample(const DevScene &S, int32_t tex, int dflt, float u, float v, bo
     float dx = tx - (float)px;
     float dy = ty - (float)py;
     const int w = (int)T.width, h = (int)T.height;
-    const int last = (int)T.count - 1;
-    int i00 = px + py * w;
-    int i01 = px + mod_inc(py, h) * w;
-    int i10 = mod_inc(px, w) + py * w;
-    int i11 = mod_inc(px, w) + mod_inc(py, h) * w;
-    // memory-safety clamp only: the reference indexes out of bounds when wrap_repeat rounds up to 1.0f
-    i00 = min(max(i00, 0), last);
-    i01 = min(max(i01, 0), last);
-    i10 = min(max(i10, 0), last);
-    i11 = min(max(i11, 0), last);
-    const uint32_t *pool = S.texels + T.offset;
-    uint32_t q00 = pool[i00], q01 = pool[i01], q10 = pool[i10], q11 = pool[i11];
+    int x0 = px, x1 = mod_inc(px, w), y0 = py, y1 = mod_inc(py, h);
+    // tiled address of texel (x, y) of this view
+    auto at = [&](int x, int y) {
+        const uint32_t tile = ((uint32_t)y >> T.th_log) * T.tiles_x + ((uint32_t)x >> T.tw_log);
+        const uint32_t within = (((uint32_t)y & ((1u << T.th_log) - 1u)) << T.tw_log) | ((uint32_t)x & ((1u << T.tw_log) - 1u));
+        return S.texels[T.offset + ((tile << (T.tw_log + T.th_log)) + within) * T.stride];
+    };
+    uint32_t q00, q01, q10, q11;
+    if (px < w && py < h) {
+        q00 = at(x0, y0), q01 = at(x0, y1), q10 = at(x1, y0), q11 = at(x1, y1);
+    } else {
+        // wrap_repeat rounded up to 1.0f: the reference indexes row-major position x + y*w past the row / the image
+        // (geometry.h:556-563); as in the oracle the flat index is clamped for memory safety only, then located
+        const int last = (int)T.count - 1;
+        auto flat = [&](int x, int y) {
+            const int i = min(max(x + y * w, 0), last);
+            return at(i % w, i / w);
+        };
+        q00 = flat(x0, y0), q01 = flat(x0, y1), q10 = flat(x1, y0), q11 = flat(x1, y1);
+    }
     st.texels(4);
     const float *rgb = gamma ? s_gam : s_lin;
     auto dec = [&](uint32_t p) { return C4{rgb[p & 255u], rgb[(p >> 8) & 255u], rgb[(p >> 16) & 255u], s_lin[p >> 24]}; };

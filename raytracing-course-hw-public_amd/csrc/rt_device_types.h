@@ -68,11 +68,20 @@ struct alignas(16) DevMaterial {
 };
 static_assert(sizeof(DevMaterial) == 64, "DevMaterial must be 64 bytes");
 
-struct DevTexture {
+// A texture VIEW: what a material slot samples. Texels are stored in tiles of 2^tw_log x 2^th_log records so that a
+// bilinear 2x2 footprint usually lies in one 128-B line, and the textures one material samples at the same (u, v)
+// (colour, normal, metallic-roughness, emissive of equal size) are interleaved record by record (stride 4 dwords: one
+// line serves all of a hit's lookups). rt_create builds the views (rt_scene.cpp build_texture_views); the values
+// Texture::sample returns are unchanged, only the addresses differ.
+struct alignas(16) DevTexture {
     uint32_t width, height;
-    uint32_t offset; // first texel in the pool
+    uint32_t offset; // pool dword of this view's texel (0,0)
     uint32_t count;  // width*height (== 1 -> Texture::sample's 1x1 fast path, geometry.h:548-550)
+    uint32_t stride; // dwords between consecutive records: 1 (stand-alone) or 4 (interleaved set)
+    uint32_t tiles_x; // tiles per row of tiles (width padded up to the tile width)
+    uint32_t tw_log, th_log;
 };
+static_assert(sizeof(DevTexture) == 32, "DevTexture must be 32 bytes");
 
 struct DevBvh {
     const DevNode *nodes;

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -264,17 +265,98 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
         o.mr_tex = m.metallic_roughness_tex;
         o.normal_tex = m.normal_tex;
     }
-    std::vector<DevTexture> texs(d->n_textures);
-    std::vector<uint32_t> pool;
-    for (uint32_t i = 0; i < d->n_textures; ++i) {
-        const rt_texture_desc &t = d->textures[i];
-        if (t.width == 0 || t.height == 0 || !t.rgba8)
+    // ---- texture views (rt_device_types.h DevTexture): tiled storage; textures one material samples together at equal
+    // size are interleaved record by record. A material slot refers to a VIEW, so materials are remapped here.
+    for (uint32_t i = 0; i < d->n_textures; ++i)
+        if (d->textures[i].width == 0 || d->textures[i].height == 0 || !d->textures[i].rgba8)
             return rt::fail(RT_ERR_INVALID_ARG, "rt_create: empty texture");
-        texs[i] = {t.width, t.height, (uint32_t)pool.size(), t.width * t.height};
-        size_t cnt = (size_t)t.width * t.height;
-        size_t base = pool.size();
-        pool.resize(base + cnt);
-        std::memcpy(pool.data() + base, t.rgba8, cnt * 4);
+    std::vector<DevTexture> texs;
+    std::vector<uint32_t> pool;
+    {
+        auto store = [&](const std::vector<int32_t> &members, uint32_t stride, std::vector<int32_t> &view_of_member) {
+            // members: texture ids of equal size (or -1 for an unused slot), one per record dword; returns view ids
+            const rt_texture_desc *first = nullptr;
+            for (int32_t t : members)
+                if (t >= 0)
+                    first = &d->textures[t];
+            const uint32_t w = first->width, h = first->height;
+            const uint32_t tw_log = stride == 1 ? 3u : 2u, th_log = stride == 1 ? 2u : 1u; // 8x4 texels or 4x2 records = 128 B
+            const uint32_t tiles_x = (w + (1u << tw_log) - 1) >> tw_log, tiles_y = (h + (1u << th_log) - 1) >> th_log;
+            const size_t base = (pool.size() + 31) & ~size_t(31); // 128-B aligned tiles
+            const size_t records = (size_t)tiles_x * tiles_y << (tw_log + th_log);
+            pool.resize(base + records * stride, 0u);
+            view_of_member.assign(members.size(), -1);
+            for (size_t k = 0; k < members.size(); ++k) {
+                if (members[k] < 0)
+                    continue;
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(d->textures[members[k]].rgba8);
+                for (uint32_t y = 0; y < h; ++y)
+                    for (uint32_t x = 0; x < w; ++x) {
+                        const size_t tile = (size_t)(y >> th_log) * tiles_x + (x >> tw_log);
+                        const size_t within = ((y & ((1u << th_log) - 1)) << tw_log) | (x & ((1u << tw_log) - 1));
+                        pool[base + ((tile << (tw_log + th_log)) + within) * stride + k] = src[(size_t)y * w + x];
+                    }
+                view_of_member[k] = (int32_t)texs.size();
+                texs.push_back(DevTexture{w, h, (uint32_t)(base + k), w * h, stride, tiles_x, tw_log, th_log});
+            }
+        };
+        std::vector<int32_t> alone(d->n_textures, -1); // stand-alone view of texture i, built on demand
+        auto alone_view = [&](int32_t t) {
+            if (alone[t] < 0) {
+                std::vector<int32_t> v;
+                store({t}, 1, v);
+                alone[t] = v[0];
+            }
+            return alone[t];
+        };
+        std::vector<std::pair<std::array<int32_t, 4>, std::array<int32_t, 4>>> sets; // slot tuple -> view ids
+        const size_t budget = (size_t)1 << 30;                                        // dwords (4 GiB) of interleaved copies
+        for (uint32_t i = 0; i < d->n_materials; ++i) {
+            DevMaterial &o = mats[i];
+            std::array<int32_t, 4> ids = {o.color_tex, o.emissive_tex, o.mr_tex, o.normal_tex}, views = {-1, -1, -1, -1};
+            bool found = false;
+            for (const auto &e : sets)
+                if (e.first == ids) {
+                    views = e.second;
+                    found = true;
+                }
+            if (!found) {
+                // the largest group of this material's textures that share a size (> 1x1) is interleaved; the rest stand alone
+                std::array<int32_t, 4> group = {-1, -1, -1, -1};
+                int best_n = 0;
+                for (int a = 0; a < 4; ++a) {
+                    if (ids[a] < 0 || d->textures[ids[a]].width * d->textures[ids[a]].height == 1)
+                        continue;
+                    std::array<int32_t, 4> g = {-1, -1, -1, -1};
+                    int n = 0;
+                    for (int b = 0; b < 4; ++b)
+                        if (ids[b] >= 0 && d->textures[ids[b]].width == d->textures[ids[a]].width && d->textures[ids[b]].height == d->textures[ids[a]].height) {
+                            g[b] = ids[b];
+                            ++n;
+                        }
+                    if (n > best_n) {
+                        best_n = n;
+                        group = g;
+                    }
+                }
+                if (best_n >= 2 && pool.size() < budget) {
+                    std::vector<int32_t> v;
+                    store({group[0], group[1], group[2], group[3]}, 4, v);
+                    for (int a = 0; a < 4; ++a)
+                        views[a] = v[a];
+                }
+                for (int a = 0; a < 4; ++a)
+                    if (ids[a] >= 0 && views[a] < 0)
+                        views[a] = alone_view(ids[a]);
+                sets.push_back({ids, views});
+            }
+            o.color_tex = views[0];
+            o.emissive_tex = views[1];
+            o.mr_tex = views[2];
+            o.normal_tex = views[3];
+        }
+        if (pool.size() >= ((size_t)1 << 32))
+            return rt::fail(RT_ERR_OOM, "rt_create: texture pool exceeds 2^32 texels");
     }
     std::vector<float> lut_lin(256), lut_gam(256);
     for (int k = 0; k < 256; ++k) {
