@@ -269,6 +269,32 @@ def test_single_texel_textures_skip_gamma(gpu, oracle, sg):
     _cmp_render(gpu, oracle, sc)
 
 
+def test_texture_views_mixed_sizes_and_sharing(gpu, oracle, sg):
+    """rt_create stores texels tiled and interleaves the equally sized textures of a material (DevTexture views); the
+    sampled values must not notice: odd sizes that are no multiple of a tile, a material whose slots differ in size,
+    1x1 slots next to real ones, one texture used by several materials in different combinations, an emissive map,
+    texcoords that wrap many times."""
+    rng = np.random.default_rng(21)
+    sc = sg.room_scene(400, seed=13, n_lights=3, n_materials=8, tex_size=0)
+
+    def tex(w, h):
+        t = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        t[..., 3] = 255
+        return t
+
+    sc.textures = [tex(5, 3), tex(5, 3), tex(5, 3), tex(9, 7), tex(16, 4), tex(1, 1), tex(9, 7), tex(33, 17), tex(33, 17)]
+    combos = [(0, 1, 2, -1), (0, 3, 2, -1), (3, 6, 4, 5), (7, 8, 5, 7), (5, 5, 5, -1), (8, -1, 7, 3), (4, 4, 4, 4), (0, 1, 2, 0)]
+    for m, (c, n, mr, e) in zip(sc.materials[2:], combos):
+        m.color_tex, m.normal_tex, m.metallic_roughness_tex, m.emissive_tex = c, n, mr, e
+        if e >= 0:
+            m.emission = (0.3, 0.2, 0.1)
+    sc.texcoords = rng.uniform(-7, 7, size=sc.texcoords.shape).astype(np.float32)
+    # exact texel-grid and wrap boundaries: u, v multiples of 1/w, integers, and values that round up to 1.0f
+    sc.texcoords[:40] = rng.integers(-3, 4, size=(40, 3, 2)).astype(np.float32) / np.float32(5)
+    sc.texcoords[40:60] = np.float32(-1e-9)
+    _cmp_render(gpu, oracle, sc, W=48, H=40, SPP=6)
+
+
 def test_shard_union_equals_single(pairs, gpu):
     """Image-row tiles sharded over G ranks: the union of the shards is bit-identical to one GPU."""
     dev, _, _ = pairs["room_plain"]
