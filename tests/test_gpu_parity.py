@@ -269,6 +269,27 @@ def test_single_texel_textures_skip_gamma(gpu, oracle, sg):
     _cmp_render(gpu, oracle, sc)
 
 
+@pytest.mark.parametrize("case", ["huge_scene", "tiny_camera_component", "tiny_box_coordinate"])
+def test_render_outside_fast_division_range(gpu, oracle, sg, case):
+    """The wavefront kernel's wave-uniform switch between the straight-line fast node step and the general step
+    (reference IEEE division): a scene scaled by 2^41 (every box coordinate beyond 2^40), a camera whose position has a
+    component of 1e-13 (every primary ray guarded, later bounces fast), and a scene with one box coordinate of 1e-13
+    (per-scene guarantee void: all rays take the exact path)."""
+    sc = sg.room_scene(300, seed=41, n_lights=3, n_materials=5, tex_size=8, n_tex_sets=2)
+    if case == "huge_scene":
+        k = np.float32(2.0**41)
+        sc.positions = (sc.positions * k).astype(np.float32)
+        sc.camera.position = (np.asarray(sc.camera.position, dtype=np.float32) * k).astype(np.float32)
+    elif case == "tiny_camera_component":
+        pos = np.asarray(sc.camera.position, dtype=np.float32).copy()
+        pos[2] = np.float32(1e-13)
+        sc.camera.position = pos
+    else:
+        sc.positions = sc.positions.copy()
+        sc.positions[20, 0, 1] = np.float32(1e-13)
+    _cmp_render(gpu, oracle, sc, W=40, H=32, SPP=4)
+
+
 def test_texture_views_mixed_sizes_and_sharing(gpu, oracle, sg):
     """rt_create stores texels tiled and interleaves the equally sized textures of a material (DevTexture views); the
     sampled values must not notice: odd sizes that are no multiple of a tile, a material whose slots differ in size,
