@@ -113,25 +113,30 @@ struct DevStats { // device-side counters, see rt_stats in include/rt_abi.h
 };
 
 // ---- wavefront pipeline (rt_wavefront.hip): path = one (pixel, sample); queues hold live rays between bounces
-struct alignas(16) WfRay { // 32 B: origin, direction, owning path
+// Queue records, one per live ray, in two parallel arrays: the ray (32 B, all wf_extend gathers) and the path's RNG
+// state (16 B). The state of a path travels WITH its ray through the queues, so wf_shade reads and writes it with the
+// coalesced queue traffic instead of a random record per hit.
+struct alignas(16) WfRay {
     float o[3];
     float dx;
     float dy, dz;
-    uint32_t path;
-    uint32_t pad;
+    uint32_t path;  // path id within the pass = index into fold / sample_out
+    uint32_t depth; // low 16 bits: remaining trace_ray budget (raytracer.h:596); high 16 bits: pending shade() frames
+};
+static_assert(sizeof(WfRay) == 32, "WfRay must be 32 bytes");
+struct alignas(16) WfRng {
+    uint32_t s[4]; // xoshiro128++ state
 };
 struct alignas(16) WfHit { // 16 B: closest hit of the ray in the same queue slot
     uint32_t k;            // DevTri index (scene-BVH order) or RT_NONE
     float b, c, t;
 };
-struct alignas(16) WfPath { // 32 B, indexed by path id: state that survives across bounces
-    uint32_t rng[4];        // xoshiro128++ state
-    uint32_t depth_left;    // remaining trace_ray budget (raytracer.h:596)
-    uint32_t nb;            // pending shade() frames = entries of this path in fold_e / fold_s
-    uint32_t pad[2];
-};
 struct alignas(16) RtF4 {
     float x, y, z, w;
+};
+struct alignas(16) WfFold { // 32 B: one pending shade() frame, `emission + inner * scale` (raytracer.h:588-590)
+    float e[3], pad0;
+    float s[3], pad1;
 };
 enum { WF_CNT_IN = 0, WF_CNT_OUT = 1, WF_CNT_TICKET = 2, WF_CNT_WORDS = 16 };
 
@@ -145,9 +150,9 @@ struct WfLaunch {
     uint64_t seed;
     float tan_x, tan_y;
     WfRay *rays_in, *rays_out;
+    WfRng *rng_in, *rng_out; // parallel to rays_in / rays_out
     WfHit *hits;
-    WfPath *paths;
-    RtF4 *fold_e, *fold_s; // [ray_depth][n_paths]: emission / scale of pending shade() frames (raytracer.h:588-590)
+    WfFold *fold;            // [ray_depth][n_paths]: pending shade() frames of every path
     RtF4 *sample_out;        // [n_paths]: sanitised radiance of each finished sample
     RtF4 *accum;             // [pass_pixels]: running per-pixel sum across sample passes (reference order)
     float *fb;               // width*height*3

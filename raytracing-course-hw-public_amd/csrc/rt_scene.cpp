@@ -111,9 +111,10 @@ struct rt_scene {
     uint32_t wf_depth_cap = 0;
     std::vector<void *> wf_owned;
     WfRay *wf_rays[2] = {nullptr, nullptr};
+    WfRng *wf_rng[2] = {nullptr, nullptr};
     WfHit *wf_hits = nullptr;
-    WfPath *wf_paths = nullptr;
-    RtF4 *wf_fold_e = nullptr, *wf_fold_s = nullptr, *wf_samples = nullptr, *wf_accum = nullptr;
+    WfFold *wf_fold = nullptr;
+    RtF4 *wf_samples = nullptr, *wf_accum = nullptr;
     uint32_t *wf_counters = nullptr;
     uint32_t *wf_sort_keys[2] = {nullptr, nullptr}, *wf_sort_vals[2] = {nullptr, nullptr};
     void *wf_sort_temp = nullptr;
@@ -138,8 +139,8 @@ struct rt_scene {
         };
         int rc;
         if ((rc = alloc(paths * sizeof(WfRay), (void **)&wf_rays[0])) != RT_OK || (rc = alloc(paths * sizeof(WfRay), (void **)&wf_rays[1])) != RT_OK ||
-            (rc = alloc(paths * sizeof(WfHit), (void **)&wf_hits)) != RT_OK || (rc = alloc(paths * sizeof(WfPath), (void **)&wf_paths)) != RT_OK ||
-            (rc = alloc(paths * depth * sizeof(RtF4), (void **)&wf_fold_e)) != RT_OK || (rc = alloc(paths * depth * sizeof(RtF4), (void **)&wf_fold_s)) != RT_OK ||
+            (rc = alloc(paths * sizeof(WfRng), (void **)&wf_rng[0])) != RT_OK || (rc = alloc(paths * sizeof(WfRng), (void **)&wf_rng[1])) != RT_OK ||
+            (rc = alloc(paths * sizeof(WfHit), (void **)&wf_hits)) != RT_OK || (rc = alloc(paths * depth * sizeof(WfFold), (void **)&wf_fold)) != RT_OK ||
             (rc = alloc(paths * sizeof(RtF4), (void **)&wf_samples)) != RT_OK || (rc = alloc(pixels * sizeof(RtF4), (void **)&wf_accum)) != RT_OK ||
             (rc = alloc(WF_CNT_WORDS * sizeof(uint32_t) + 1024, (void **)&wf_counters)) != RT_OK)
             return rc;
@@ -523,13 +524,13 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
     if (L.n_items > 0 && wavefront) {
         // ---- production path: wavefront pipeline over (pixel tile) x (sample range) passes, all stream-ordered
         // Paths per pass: the larger a pass, the smaller the share of each bounce launch's drain phase (measured on
-        // S-sponza 1000x1000x64: 8 M paths 148, 16 M 158, 32 M 164, 64 M 167 Msamples/s). 64 M paths x 384 B = 25.8 GB
+        // S-sponza 1000x1000x64: 8 M paths 148, 16 M 158, 32 M 164, 64 M 167 Msamples/s). 64 M paths x 400 B = 26.8 GB
         // of workspace, sized for 288 GB of HBM; capped by free device memory below.
         uint64_t max_paths = 64ull << 20;
         {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                const uint64_t per_path = 2 * sizeof(WfRay) + sizeof(WfHit) + sizeof(WfPath) + (2ull * s->dev.ray_depth + 1) * sizeof(RtF4);
+                const uint64_t per_path = 2 * (sizeof(WfRay) + sizeof(WfRng)) + sizeof(WfHit) + s->dev.ray_depth * sizeof(WfFold) + sizeof(RtF4) + 16 /* sort keys + slots */;
                 const uint64_t have = free_b + s->wf_paths_cap * per_path; // what is already ours can be reused
                 const uint64_t fit = (uint64_t)(0.6 * (double)have) / per_path;
                 max_paths = std::max<uint64_t>(1u << 16, std::min(max_paths, fit));
@@ -555,10 +556,10 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
         W.tan_y = L.tan_y;
         W.rays_in = s->wf_rays[0];
         W.rays_out = s->wf_rays[1];
+        W.rng_in = s->wf_rng[0];
+        W.rng_out = s->wf_rng[1];
         W.hits = s->wf_hits;
-        W.paths = s->wf_paths;
-        W.fold_e = s->wf_fold_e;
-        W.fold_s = s->wf_fold_s;
+        W.fold = s->wf_fold;
         W.sample_out = s->wf_samples;
         W.accum = s->wf_accum;
         W.fb = d_fb;

@@ -80,20 +80,12 @@ template <bool STATS> __global__ __launch_bounds__(256) void wf_generate(const D
         r.o[0] = cam_pos.x, r.o[1] = cam_pos.y, r.o[2] = cam_pos.z;
         r.dx = rd.x, r.dy = rd.y, r.dz = rd.z;
         r.path = i;
-        r.pad = 0;
-        WfPath p;
-        p.rng[0] = rng.g.s[0], p.rng[1] = rng.g.s[1], p.rng[2] = rng.g.s[2], p.rng[3] = rng.g.s[3];
-        p.depth_left = L.ray_depth;
-        p.nb = 0;
-        p.pad[0] = p.pad[1] = 0;
+        r.depth = L.ray_depth; // no pending frames yet
         float4 *rq = reinterpret_cast<float4 *>(L.rays_in + i);
         const float4 *rs = reinterpret_cast<const float4 *>(&r);
         rq[0] = rs[0];
         rq[1] = rs[1];
-        float4 *pq = reinterpret_cast<float4 *>(L.paths + i);
-        const float4 *ps = reinterpret_cast<const float4 *>(&p);
-        pq[0] = ps[0];
-        pq[1] = ps[1];
+        *reinterpret_cast<uint4 *>(L.rng_in + i) = make_uint4(rng.g.s[0], rng.g.s[1], rng.g.s[2], rng.g.s[3]);
         st.cast(); // ray_depth >= 1: trace_ray casts (raytracer.h:600)
     }
     st.flush(L.stats);
@@ -285,16 +277,16 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
         const bool active = j < n_in;
         bool survive = false;
         WfRay nr;
+        uint4 nrng = make_uint4(0u, 0u, 0u, 0u);
         if (active) {
             const float4 *rq = reinterpret_cast<const float4 *>(L.rays_in + j);
             const float4 r0 = rq[0], r1 = rq[1];
+            const uint4 p0 = *reinterpret_cast<const uint4 *>(L.rng_in + j);
             const float4 hq = *reinterpret_cast<const float4 *>(L.hits + j);
             const uint32_t path = __float_as_uint(r1.z);
-            const float4 *pq = reinterpret_cast<const float4 *>(L.paths + path);
-            const float4 p0 = pq[0], p1 = pq[1];
             Rng<RT_RNG_DEVICE> rng;
-            rng.g.s[0] = __float_as_uint(p0.x), rng.g.s[1] = __float_as_uint(p0.y), rng.g.s[2] = __float_as_uint(p0.z), rng.g.s[3] = __float_as_uint(p0.w);
-            uint32_t depth_left = __float_as_uint(p1.x), nb = __float_as_uint(p1.y);
+            rng.g.s[0] = p0.x, rng.g.s[1] = p0.y, rng.g.s[2] = p0.z, rng.g.s[3] = p0.w;
+            uint32_t depth_left = __float_as_uint(r1.w) & 0xFFFFu, nb = __float_as_uint(r1.w) >> 16;
             Hit h;
             h.k = __float_as_uint(hq.x), h.b = hq.y, h.c = hq.z, h.t = hq.w;
             if (h.k != RT_NONE)
@@ -303,8 +295,9 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
             bool terminal = sr.terminal;
             V3 term = sr.term;
             if (sr.push) { // emission + trace_ray(...) * scl (raytracer.h:588-590), folded when the path ends
-                L.fold_e[(size_t)nb * L.n_paths + path] = RtF4{sr.emission.x, sr.emission.y, sr.emission.z, 0.f};
-                L.fold_s[(size_t)nb * L.n_paths + path] = RtF4{sr.scl.x, sr.scl.y, sr.scl.z, 0.f};
+                float4 *fw = reinterpret_cast<float4 *>(L.fold + ((size_t)nb * L.n_paths + path));
+                fw[0] = make_float4(sr.emission.x, sr.emission.y, sr.emission.z, 0.f);
+                fw[1] = make_float4(sr.scl.x, sr.scl.y, sr.scl.z, 0.f);
                 ++nb;
             }
             if (!terminal && depth_left == 0) { // trace_ray(..., 0) returns (0,0,0) without casting (:596-598)
@@ -315,8 +308,8 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
                 V3 res = term;
                 while (nb > 0) { // unwind the pending shade() frames: emission + inner * scl
                     --nb;
-                    const RtF4 fs = L.fold_s[(size_t)nb * L.n_paths + path];
-                    const RtF4 fe = L.fold_e[(size_t)nb * L.n_paths + path];
+                    const float4 *fr = reinterpret_cast<const float4 *>(L.fold + ((size_t)nb * L.n_paths + path));
+                    const float4 fe = fr[0], fs = fr[1];
                     V3 clr = res * mk(fs.x, fs.y, fs.z);
                     res = mk(fe.x, fe.y, fe.z) + clr;
                 }
@@ -334,16 +327,8 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
                 nr.o[0] = sr.nro.x, nr.o[1] = sr.nro.y, nr.o[2] = sr.nro.z;
                 nr.dx = sr.nrd.x, nr.dy = sr.nrd.y, nr.dz = sr.nrd.z;
                 nr.path = path;
-                nr.pad = 0;
-                WfPath p;
-                p.rng[0] = rng.g.s[0], p.rng[1] = rng.g.s[1], p.rng[2] = rng.g.s[2], p.rng[3] = rng.g.s[3];
-                p.depth_left = depth_left;
-                p.nb = nb;
-                p.pad[0] = p.pad[1] = 0;
-                float4 *pw = reinterpret_cast<float4 *>(L.paths + path);
-                const float4 *ps = reinterpret_cast<const float4 *>(&p);
-                pw[0] = ps[0];
-                pw[1] = ps[1];
+                nr.depth = depth_left | (nb << 16);
+                nrng = make_uint4(rng.g.s[0], rng.g.s[1], rng.g.s[2], rng.g.s[3]);
             }
         }
         // compact the survivors of this wave into the next queue: ballot + prefix sum, one atomic per wave
@@ -360,6 +345,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
                 const float4 *rs = reinterpret_cast<const float4 *>(&nr);
                 rw[0] = rs[0];
                 rw[1] = rs[1];
+                *reinterpret_cast<uint4 *>(L.rng_out + obase + rank) = nrng;
             }
         }
     }
@@ -498,6 +484,9 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         WfRay *t = L.rays_in;
         L.rays_in = L.rays_out;
         L.rays_out = t;
+        WfRng *tr = L.rng_in;
+        L.rng_in = L.rng_out;
+        L.rng_out = tr;
     }
     const int res_blocks = (int)((L.pass_pixels + 255u) / 256u);
     hipLaunchKernelGGL(wf_resolve, dim3(res_blocks > 0 ? res_blocks : 1), block, 0, stream, L, first_pass ? 1 : 0, last_pass ? 1 : 0);
