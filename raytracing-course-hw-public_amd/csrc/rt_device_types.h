@@ -152,7 +152,7 @@ struct WfLaunch {
     WfRay *rays_in, *rays_out;
     WfRng *rng_in, *rng_out; // parallel to rays_in / rays_out
     WfHit *hits;
-    WfFold *fold;            // [ray_depth][n_paths]: pending shade() frames of every path
+    WfFold *fold;            // [n_paths][ray_depth]: pending shade() frames, a path's frames contiguous (its unwind reads 1-2 lines)
     RtF4 *sample_out;        // [n_paths]: sanitised radiance of each finished sample
     RtF4 *accum;             // [pass_pixels]: running per-pixel sum across sample passes (reference order)
     float *fb;               // width*height*3

@@ -295,7 +295,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
             bool terminal = sr.terminal;
             V3 term = sr.term;
             if (sr.push) { // emission + trace_ray(...) * scl (raytracer.h:588-590), folded when the path ends
-                float4 *fw = reinterpret_cast<float4 *>(L.fold + ((size_t)nb * L.n_paths + path));
+                float4 *fw = reinterpret_cast<float4 *>(L.fold + ((size_t)path * L.ray_depth + nb));
                 fw[0] = make_float4(sr.emission.x, sr.emission.y, sr.emission.z, 0.f);
                 fw[1] = make_float4(sr.scl.x, sr.scl.y, sr.scl.z, 0.f);
                 ++nb;
@@ -308,7 +308,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
                 V3 res = term;
                 while (nb > 0) { // unwind the pending shade() frames: emission + inner * scl
                     --nb;
-                    const float4 *fr = reinterpret_cast<const float4 *>(L.fold + ((size_t)nb * L.n_paths + path));
+                    const float4 *fr = reinterpret_cast<const float4 *>(L.fold + ((size_t)path * L.ray_depth + nb));
                     const float4 fe = fr[0], fs = fr[1];
                     V3 clr = res * mk(fs.x, fs.y, fs.z);
                     res = mk(fe.x, fe.y, fe.z) + clr;
