@@ -44,6 +44,20 @@ template <class T> int upload(const std::vector<T> &v, const T **out, std::vecto
     return RT_OK;
 }
 
+// device allocation that is released on every return path of the probe entry points
+struct DevBuf {
+    void *p = nullptr;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+    ~DevBuf() {
+        if (p)
+            (void)hipFree(p);
+    }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
 struct V3h {
     float x, y, z;
 };
@@ -685,11 +699,12 @@ extern "C" int rt_cast_rays(rt_scene *s, const float *rays, uint32_t n, uint32_t
     if (n == 0)
         return RT_OK;
     HIP_TRY(hipSetDevice(s->device));
-    float *d_rays = nullptr, *d_bct = nullptr;
-    uint32_t *d_prim = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_rays, (size_t)n * 24));
-    HIP_TRY(hipMalloc((void **)&d_bct, (size_t)n * 12));
-    HIP_TRY(hipMalloc((void **)&d_prim, (size_t)n * 4));
+    DevBuf b_rays, b_bct, b_prim;
+    HIP_TRY(b_rays.alloc((size_t)n * 24));
+    HIP_TRY(b_bct.alloc((size_t)n * 12));
+    HIP_TRY(b_prim.alloc((size_t)n * 4));
+    float *d_rays = b_rays.as<float>(), *d_bct = b_bct.as<float>();
+    uint32_t *d_prim = b_prim.as<uint32_t>();
     int rc = RT_OK;
     hipError_t e = hipMemcpy(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice);
     if (e == hipSuccess)
@@ -702,9 +717,6 @@ extern "C" int rt_cast_rays(rt_scene *s, const float *rays, uint32_t n, uint32_t
         e = hipMemcpy(bct_out, d_bct, (size_t)n * 12, hipMemcpyDeviceToHost);
     if (e != hipSuccess)
         rc = rt::fail(RT_ERR_HIP, std::string("rt_cast_rays: ") + hipGetErrorString(e));
-    (void)hipFree(d_rays);
-    (void)hipFree(d_bct);
-    (void)hipFree(d_prim);
     return rc;
 }
 
@@ -714,9 +726,10 @@ extern "C" int rt_light_pdf(rt_scene *s, const float *rays, uint32_t n, float *p
     if (n == 0)
         return RT_OK;
     HIP_TRY(hipSetDevice(s->device));
-    float *d_rays = nullptr, *d_pdf = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_rays, (size_t)n * 24));
-    HIP_TRY(hipMalloc((void **)&d_pdf, (size_t)n * 4));
+    DevBuf b_rays, b_pdf;
+    HIP_TRY(b_rays.alloc((size_t)n * 24));
+    HIP_TRY(b_pdf.alloc((size_t)n * 4));
+    float *d_rays = b_rays.as<float>(), *d_pdf = b_pdf.as<float>();
     int rc = RT_OK;
     hipError_t e = hipMemcpy(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice);
     if (e == hipSuccess)
@@ -727,8 +740,6 @@ extern "C" int rt_light_pdf(rt_scene *s, const float *rays, uint32_t n, float *p
         e = hipMemcpy(pdf_out, d_pdf, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess)
         rc = rt::fail(RT_ERR_HIP, std::string("rt_light_pdf: ") + hipGetErrorString(e));
-    (void)hipFree(d_rays);
-    (void)hipFree(d_pdf);
     return rc;
 }
 
