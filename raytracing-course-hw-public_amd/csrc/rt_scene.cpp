@@ -104,7 +104,8 @@ struct rt_scene {
             void *q = nullptr;
             HIP_TRY(hipMalloc(&q, sizeof(t)));
             d_film_table = static_cast<rt::FilmTable *>(q);
-            HIP_TRY(hipMemcpy(d_film_table, &t, sizeof(t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpyAsync(d_film_table, &t, sizeof(t), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream)); // `t` is a local
         }
         if (rgb8_capacity < rgb8_bytes) {
             if (d_rgb8)
@@ -163,7 +164,9 @@ struct rt_scene {
             (rc = alloc(paths * 4, (void **)&wf_sort_vals[0])) != RT_OK || (rc = alloc(paths * 4, (void **)&wf_sort_vals[1])) != RT_OK ||
             (rc = alloc(wf_sort_temp_bytes, &wf_sort_temp)) != RT_OK)
             return rc;
-        (void)hipMemset(wf_counters, 0, WF_CNT_WORDS * sizeof(uint32_t) + 1024);
+        // on the scene's own (non-blocking) stream: a null-stream memset is not ordered with the kernels launched there and
+        // could land after wf_generate had set the queue size
+        HIP_TRY(hipMemsetAsync(wf_counters, 0, WF_CNT_WORDS * sizeof(uint32_t) + 1024, stream));
         wf_paths_cap = paths;
         wf_pixels_cap = pixels;
         wf_depth_cap = depth;
@@ -429,6 +432,9 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
     HIP_TRY(hipMalloc(&p, sizeof(DevStats)));
     s->owned.push_back(p);
     s->d_stats = static_cast<DevStats *>(p);
+    // the uploads above went through the null stream; the scene's stream is non-blocking (not ordered with it), so make
+    // sure everything has landed before the first kernel can be launched
+    HIP_TRY(hipDeviceSynchronize());
     return RT_OK;
 }
 
@@ -706,15 +712,16 @@ extern "C" int rt_cast_rays(rt_scene *s, const float *rays, uint32_t n, uint32_t
     float *d_rays = b_rays.as<float>(), *d_bct = b_bct.as<float>();
     uint32_t *d_prim = b_prim.as<uint32_t>();
     int rc = RT_OK;
-    hipError_t e = hipMemcpy(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice);
+    // every copy is ordered on the scene's own (non-blocking) stream with the kernel
+    hipError_t e = hipMemcpyAsync(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice, s->stream);
     if (e == hipSuccess)
         e = rt::launch_cast(s->dev, d_rays, n, d_prim, d_bct, s->stream);
     if (e == hipSuccess)
+        e = hipMemcpyAsync(prim_out, d_prim, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(bct_out, d_bct, (size_t)n * 12, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess)
         e = hipStreamSynchronize(s->stream);
-    if (e == hipSuccess)
-        e = hipMemcpy(prim_out, d_prim, (size_t)n * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess)
-        e = hipMemcpy(bct_out, d_bct, (size_t)n * 12, hipMemcpyDeviceToHost);
     if (e != hipSuccess)
         rc = rt::fail(RT_ERR_HIP, std::string("rt_cast_rays: ") + hipGetErrorString(e));
     return rc;
@@ -731,13 +738,13 @@ extern "C" int rt_light_pdf(rt_scene *s, const float *rays, uint32_t n, float *p
     HIP_TRY(b_pdf.alloc((size_t)n * 4));
     float *d_rays = b_rays.as<float>(), *d_pdf = b_pdf.as<float>();
     int rc = RT_OK;
-    hipError_t e = hipMemcpy(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpyAsync(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice, s->stream);
     if (e == hipSuccess)
         e = rt::launch_light_pdf(s->dev, d_rays, n, d_pdf, s->stream);
     if (e == hipSuccess)
-        e = hipStreamSynchronize(s->stream);
+        e = hipMemcpyAsync(pdf_out, d_pdf, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess)
-        e = hipMemcpy(pdf_out, d_pdf, (size_t)n * 4, hipMemcpyDeviceToHost);
+        e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess)
         rc = rt::fail(RT_ERR_HIP, std::string("rt_light_pdf: ") + hipGetErrorString(e));
     return rc;
@@ -776,6 +783,7 @@ extern "C" int rt_debug_census(rt_scene *s, unsigned long long *out32) {
         return RT_ERR_INVALID_ARG;
     if (hipMemcpy(out32, s->wf_counters + 64, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
         return RT_ERR_HIP;
-    (void)hipMemset(s->wf_counters + 64, 0, 32 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(s->wf_counters + 64, 0, 32 * sizeof(unsigned long long), s->stream);
+    (void)hipStreamSynchronize(s->stream);
     return RT_OK;
 }

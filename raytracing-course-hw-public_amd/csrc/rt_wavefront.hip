@@ -114,12 +114,19 @@ DEV void leaf_batch(Trav &T, const DevBvh &bvh, bool at_leaf, uint16_t *s_owner,
         off += below << b;
         total += (uint32_t)__popcll(m) << b;
     }
+    // Owner table: position off + t belongs to (lane, t) for t < n. Every waiting lane writes ALL RT_LEAF_COOP_MAX
+    // entries, highest t first, without a per-entry predicate: an entry with t >= n lands on position off' + t' of a
+    // later lane (off' > off, hence t' < t), whose own store of that position is issued LATER (a wave's LDS
+    // instructions execute in order) and wins; within one instruction the waiting lanes' positions are distinct
+    // (their offsets increase strictly). Positions >= total are never read; the table has room for the overshoot.
+    if (at_leaf) {
 #pragma unroll
-    for (uint32_t t = 0; t < RT_LEAF_COOP_MAX; ++t)
-        if (t < n)
-            s_owner[off + t] = (uint16_t)(lane | (t << 8));
-    if (at_leaf)
+        for (int t = RT_LEAF_COOP_MAX - 1; t >= 0; --t) {
+            s_owner[off + t] = (uint16_t)(lane | ((uint32_t)t << 8));
+            asm volatile("" ::: "memory"); // keep the stores in this order (compiler and machine scheduler)
+        }
         s_min[lane] = ~0ull;
+    }
     __threadfence_block();
     const uint32_t k0 = T.cur & RT_LEAF_BEGIN_MASK;
     DIAG(13, 1);
@@ -174,7 +181,7 @@ DEV void leaf_batch(Trav &T, const DevBvh &bvh, bool at_leaf, uint16_t *s_owner,
 
 template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) void wf_extend(const DevScene S, const WfLaunch L) {
     __shared__ uint32_t s_stack[STACK_LDS_DWORDS_FOR(RT_EXT_LDS_DEPTH)];
-    __shared__ uint16_t s_owner_all[4][64 * RT_LEAF_COOP_MAX];
+    __shared__ uint16_t s_owner_all[4][64 * RT_LEAF_COOP_MAX + RT_LEAF_COOP_MAX]; // + overshoot of the unpredicated owner stores
     __shared__ unsigned long long s_min_all[4][64];
     __shared__ float2 s_bc_all[4][64];
     const uint32_t wave = threadIdx.x >> 6;

@@ -201,7 +201,18 @@ def test_full_size_bench_scene_parity(gpu, oracle, sg):
                 os.environ[k] = v
     assert np.array_equal(b.view(np.uint32), a.view(np.uint32))
     assert np.isfinite(a).all() and a.mean() > 1e-4
+    # a second and a third scene in the same process, their FIRST render being a sorted wavefront render: the workspace
+    # set-up of a new scene must be ordered with its own stream (regression: a null-stream memset of the queue counters
+    # raced with the first launches on the scene's non-blocking stream)
+    dev2 = gpu.DeviceScene(sc)
+    a2, _ = dev2.run_raytracer(W, H, 8, seed=7)
+    assert np.array_equal(a2.view(np.uint32), a.view(np.uint32))
     dev.close()
+    dev3 = gpu.DeviceScene(sc)
+    a3, _ = dev3.run_raytracer(W, H, 8, seed=7, counters=True)
+    assert np.array_equal(a3.view(np.uint32), a.view(np.uint32))
+    dev2.close()
+    dev3.close()
 
 
 def _cmp_render(gpu, oracle, sc, W=40, H=36, SPP=5, seed=3):
