@@ -327,45 +327,6 @@ template <int LDS_DEPTH> struct StackMemT {
         return ref;
     }
 };
-// Array-member variant (the whole object lives in scratch; LDS accesses go through generic pointers). Kept for the
-// parity megakernel and the probe kernels of rt_kernels.hip, where the pointer-only form trips a gfx950 backend error
-// ("Operand has incorrect register class", ROCm 7.2); those kernels are not on the timed path.
-template <int LDS_DEPTH> struct StackMemArrT {
-    uint32_t *lds;
-    uint32_t ov_ref[RT_MAX_STACK - LDS_DEPTH];
-    float ov_d[RT_MAX_STACK - LDS_DEPTH];
-    float ov_loc[RT_MAX_STACK - LDS_DEPTH];
-    DEV void push(int sp, uint32_t ref, float d, float loc) {
-        if (sp < LDS_DEPTH) {
-            lds[(0 * LDS_DEPTH + sp) * 256] = ref;
-            lds[(1 * LDS_DEPTH + sp) * 256] = __float_as_uint(d);
-            lds[(2 * LDS_DEPTH + sp) * 256] = __float_as_uint(loc);
-        } else {
-            ov_ref[sp - LDS_DEPTH] = ref;
-            ov_d[sp - LDS_DEPTH] = d;
-            ov_loc[sp - LDS_DEPTH] = loc;
-        }
-    }
-    DEV void pop(int sp, uint32_t &ref, float &d, float &loc) {
-        if (sp < LDS_DEPTH) {
-            ref = lds[(0 * LDS_DEPTH + sp) * 256];
-            d = __uint_as_float(lds[(1 * LDS_DEPTH + sp) * 256]);
-            loc = __uint_as_float(lds[(2 * LDS_DEPTH + sp) * 256]);
-        } else {
-            ref = ov_ref[sp - LDS_DEPTH];
-            d = ov_d[sp - LDS_DEPTH];
-            loc = ov_loc[sp - LDS_DEPTH];
-        }
-    }
-    DEV void push_ref(int sp, uint32_t ref) {
-        if (sp < LDS_DEPTH)
-            lds[(0 * LDS_DEPTH + sp) * 256] = ref;
-        else
-            ov_ref[sp - LDS_DEPTH] = ref;
-    }
-    DEV uint32_t pop_ref(int sp) { return sp < LDS_DEPTH ? lds[(0 * LDS_DEPTH + sp) * 256] : ov_ref[sp - LDS_DEPTH]; }
-};
-using StackMem = StackMemArrT<LDS_DEPTH>;
 #define STACK_LDS_DWORDS (3 * LDS_DEPTH * 256)
 #define STACK_LDS_DWORDS_FOR(depth) (3 * (depth) * 256)
 #define RT_DECLARE_STACK(NAME, DEPTH, SHARED_ARRAY)          \

@@ -77,8 +77,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const De
 #endif
     LaneStats<STATS> st;
     Rng<MODE> rng;
-    StackMem stk;
-    stk.lds = s_stack + threadIdx.x;
+    RT_DECLARE_STACK(stk, LDS_DEPTH, s_stack);
     float fold_e[RT_MAX_RAY_DEPTH * 3];
     float fold_s[RT_MAX_RAY_DEPTH * 3];
 
@@ -226,8 +225,7 @@ __global__ __launch_bounds__(256) void cast_kernel(const DevScene S, const float
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    StackMem stk;
-    stk.lds = s_stack + threadIdx.x;
+    RT_DECLARE_STACK(stk, LDS_DEPTH, s_stack);
     LaneStats<false> st;
     Trav T;
     trav_init(T, S.scene, ld3(rays + 6ull * i), ld3(rays + 6ull * i + 3));
@@ -250,8 +248,7 @@ __global__ __launch_bounds__(256) void light_pdf_kernel(const DevScene S, const 
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    StackMem stk;
-    stk.lds = s_stack + threadIdx.x;
+    RT_DECLARE_STACK(stk, LDS_DEPTH, s_stack);
     LaneStats<false> st;
     V3 o = ld3(rays + 6ull * i), d = ld3(rays + 6ull * i + 3);
     pdf_out[i] = S.lights.n_tris ? lights_pdf<false>(S, o, d, stk, st) : 0.0f;
