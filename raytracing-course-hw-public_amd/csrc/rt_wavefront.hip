@@ -8,8 +8,9 @@
 //   wf_generate : gen_ray (raytracer.h:527-538) for every path of the pass -> ray queue
 //   per bounce (ray_depth times):
 //     wf_extend : closest hit (BVH::intersect_ray, bvh.h:195-235) for every queued ray. Persistent wavefronts; a lane
-//                 whose traversal ends stores its hit and is refilled from the queue (wave ballot + prefix count, one
-//                 ticket atomic per refill), so the wave stays dense whatever the spread of traversal lengths.
+//                 whose traversal ends stores its hit and is refilled from the queue (wave ballot + prefix count out of
+//                 the wave's private chunk of queue positions, one ticket atomic per 128-ray chunk), so the wave stays
+//                 dense whatever the spread of traversal lengths. Bounces >= 1 walk the queue in a coherence-sorted order.
 //     wf_shade  : one shade() level (raytracer.h:555-591) per hit: texture fetches, sampling, pdfs (incl. the light-BVH
 //                 traversal), BRDF. Finished paths fold their (emission, scale) frames back-to-front (the Horner order of
 //                 raytracer.h:588-590) and store the sample; surviving paths are COMPACTED into the next ray queue with
@@ -18,7 +19,8 @@
 //                 float sum has exactly the reference's order (raytracer.h:621-626) although samples ran in parallel.
 //
 // Every path owns an xoshiro128++ stream seeded from (seed, pixel, sample) and consumes it in the reference's draw
-// order, so the image is independent of queue order, tiling and GPU count, and bit-identical to the persistent
+// order; the stream's state, the remaining depth and the count of pending frames travel with the ray through the queues
+// (WfRay / WfRng), so the image is independent of queue order, tiling and GPU count, and bit-identical to the persistent
 // megakernel of rt_kernels.hip and to the CPU oracle in device-RNG mode.
 #include <cstring>
 #include <vector>
@@ -93,7 +95,8 @@ template <bool STATS> __global__ __launch_bounds__(256) void wf_generate(const D
 
 // ------------------------------------------------------------------------------------------------ extend
 // Closest hit for every queued ray. Two kinds of work alternate inside a wave instead of being interleaved:
-//   * node steps   : lanes standing on an inner node test its two child boxes (trav_step), lanes that reached a leaf wait;
+//   * node steps   : lanes standing on an inner node test its two child boxes (trav_step_inner_fast; trav_step_core for a
+//                    wave with a guarded ray or a big-leaf walker), lanes that reached a leaf wait;
 //   * leaf batches : once enough lanes wait on leaves (or nobody is left on inner nodes) the wave tests ALL their
 //                    triangles together: the (ray, triangle) pairs of the waiting lanes are laid out densely over the
 //                    64 lanes (prefix sum of the leaf sizes), each lane fetches "its" ray from the owning lane with
@@ -101,7 +104,7 @@ template <bool STATS> __global__ __launch_bounds__(256) void wf_generate(const D
 //                    (t bits, triangle index) reduced with LDS atomics, i.e. smallest t and, on equal t, the
 //                    lowest triangle index — exactly the leaf loop's strict-less replacement order (bvh.h:200-204,132).
 // This removes the inner-node / triangle divergence of a one-record-per-lane step (about 58 % / 42 % of the lanes) and
-// packs the triangle tests: a wave does ~45 node tests or ~60 triangle tests per pass instead of ~32 + ~24.
+// packs the triangle tests: a wave does ~40 node tests or ~48 triangle tests per pass instead of ~27 + ~20.
 template <bool STATS>
 DEV void leaf_batch(Trav &T, const DevBvh &bvh, bool at_leaf, uint16_t *s_owner, unsigned long long *s_min, float2 *s_bc, LaneStats<STATS> &st) {
     const uint32_t lane = threadIdx.x & 63u;
