@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
 
 import importlib  # noqa: E402
 
@@ -36,10 +37,19 @@ N_RAYS = 4096
 
 def main():
     assert oracle.have_reference_build(), "build oracle/_ref first (make -C oracle)"
-    for name, spec in golden_scene_specs().items():
-        sc = make_scene(rt.scenegen, spec)
+    import make_features_gltf
+
+    jobs = [(name, spec) for name, spec in golden_scene_specs().items()] + [("features", None)]
+    for name, spec in jobs:
         with tempfile.TemporaryDirectory() as td:
-            gltf = rt.scenegen.write_gltf(sc, os.path.join(td, name + ".gltf"))
+            if spec is None:  # the hand-built loader-feature scene: the glTF itself is a committed fixture
+                gltf = make_features_gltf.build(os.path.join(HERE, "features"))
+                import types
+
+                sc = types.SimpleNamespace(positions=rt.parse_gltf_scene(gltf, W / H).arrays()["positions"])  # bounds for the random rays
+            else:
+                sc = make_scene(rt.scenegen, spec)
+                gltf = rt.scenegen.write_gltf(sc, os.path.join(td, name + ".gltf"))
             ppm = os.path.join(HERE, f"{name}_{W}x{H}x{SPP}.ppm")
             oracle.run_reference(gltf, W, H, SPP, ppm)
             # BVHs

@@ -411,6 +411,29 @@ def test_reference_rng_mode_close_to_reference_binary_golden(gpu, sg, oracle, tm
         dev.close()
 
 
+def test_feature_gltf_through_loader_matches_oracle_and_reference(gpu, oracle):
+    """The hand-built loader-feature glTF (tests/golden/features: scene selection, matrix + TRS nodes, strips, u8/u16/u32
+    indices, missing attributes, emissive texture + strength, mixed texture sizes) through the C++ loader onto the GPU:
+    bit-exact against the oracle in device-RNG mode, and in reference-RNG mode close to the PPM the unmodified reference
+    binary produced (only sin/cos last-bit differences remain, as in the other golden comparisons)."""
+    import os
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ls = gpu.parse_gltf_scene(os.path.join(gold, "features", "features.gltf"), 64 / 48)
+    dev, orc = gpu.DeviceScene(ls), oracle.OracleScene(ls)
+    g, gs = dev.run_raytracer(64, 48, 6, seed=17, counters=True)
+    o, os_ = orc.run_raytracer(64, 48, 6, seed=17)
+    assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+    for k in ("casts", "nodes_visited", "tri_tests", "shaded_hits", "texel_fetches", "light_tri_tests"):
+        assert gs[k] == os_[k], k
+    img, _ = dev.run_raytracer_rgb8(64, 48, 4, rng_mode=gpu.RT_RNG_REFERENCE)
+    ref = oracle.read_ppm(os.path.join(gold, "features_64x48x4.ppm"))
+    differing = int((img != ref).any(axis=2).sum())
+    assert differing <= 0.02 * 64 * 48, f"{differing} of {64 * 48} pixels differ from the reference binary's PPM"
+    dev.close()
+    orc.close()
+
+
 # ------------------------------------------------------------------------------------------------ device film (8f-3)
 def _film_edge_values():
     rng = np.random.default_rng(12)

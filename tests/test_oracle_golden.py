@@ -12,7 +12,10 @@ import pytest
 from conftest import golden_scene_specs, make_scene
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-NAMES = list(golden_scene_specs().keys())
+GENERATED = list(golden_scene_specs().keys())
+# "features": hand-built glTF committed under tests/golden/features/ (scene selection, matrix + TRS nodes, strips,
+# u8/u16/u32 indices, missing attributes, lower-case `tangent`, emissive texture + strength, ...; make_features_gltf.py)
+NAMES = GENERATED + ["features"]
 W, H, SPP = 64, 48, 4
 
 
@@ -25,6 +28,8 @@ def loaded(rt, sg, tmp_path_factory):
         sc = make_scene(sg, spec)
         path = sg.write_gltf(sc, str(d / (name + ".gltf")))
         out[name] = (rt.parse_gltf_scene(path, W / H), sc, path)
+    path = os.path.join(GOLD, "features", "features.gltf")
+    out["features"] = (rt.parse_gltf_scene(path, W / H), None, path)
     return out
 
 
@@ -53,7 +58,7 @@ def test_loader_matches_reference_scene_objects(loaded, name):
     assert np.array_equal(cam.view(np.uint32), g["camera"].view(np.uint32))
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", GENERATED)
 def test_loader_matches_python_generator(loaded, rt, name):
     """The direct-ABI path (numpy arrays -> rt_scene_desc, used by bench.py) feeds the same triangles as the glTF path."""
     ls, sc, _ = loaded[name]
