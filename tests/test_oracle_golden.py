@@ -178,3 +178,16 @@ def test_live_reference_binary_if_present(oracle, rt, sg, tmp_path):
     orc = oracle.OracleScene(ls)
     fb, _ = orc.run_raytracer(40, 56, 3, rng_mode=rt.RT_RNG_REFERENCE)
     assert np.array_equal(oracle.tonemap(fb), ref)
+
+
+def test_live_reference_binary_on_a_deep_tree_if_present(oracle, rt, sg, tmp_path):
+    """Same as above at 30 000 triangles (a BVH ~20 levels deep, textured, dense overlaps): the oracle's PPM must still be
+    byte-identical to the reference binary's. Container only (needs oracle/_ref)."""
+    if not oracle.have_reference_build():
+        pytest.skip("oracle/_ref not built (GPU box): covered by the committed fixtures")
+    sc = sg.room_scene(30000, seed=4711, n_lights=6, n_materials=12, tex_size=16, n_tex_sets=4, alpha_fraction=0.1, offset=0.4)
+    path = sg.write_gltf(sc, str(tmp_path / "deep.gltf"))
+    ref = oracle.run_reference(path, 96, 64, 2, str(tmp_path / "ref.ppm"))
+    ls = rt.parse_gltf_scene(path, 96 / 64)
+    fb, _ = oracle.OracleScene(ls).run_raytracer(96, 64, 2, rng_mode=rt.RT_RNG_REFERENCE)
+    assert np.array_equal(oracle.tonemap(fb), ref)
