@@ -189,6 +189,11 @@ def main() -> None:
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic,
+        # HBM-side rate from the PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_hbm_traffic.json) over the live launch
+        # duration: what the memory system actually moved, next to the algorithmic figure above (cache hits included)
+        "traffic_rate": round(traffic / avg_launch_s / 1e9, 2) if traffic else None,
+        "traffic_frac": round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+        "peak_measured_read": 6023.0,  # tools/ubench/hbm_stream.hip on this box class (profiles/r01_hbm_stream.txt); nominal peak above
         "kernel": "wf_extend<false>",
         "launches_per_step": launches_per_render,
         "avg_launch_ms": round(avg_launch_s * 1e3, 4),
