@@ -301,6 +301,50 @@ def test_render_outside_fast_division_range(gpu, oracle, sg, case):
     _cmp_render(gpu, oracle, sc, W=40, H=32, SPP=4)
 
 
+def _tiny_scene(sg, n_tris, seed):
+    """n_tris triangles in front of a camera at the origin looking down -z; the last one is emissive."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform([-2.0, -1.5, -7.0], [2.0, 1.5, -4.0], size=(n_tris, 1, 3))
+    pos = (c + rng.uniform(-2.0, 2.0, size=(n_tris, 3, 3)) * np.array([1.0, 1.0, 0.3])).astype(np.float32)
+    mats = [sg.Material(color=(0.7, 0.6, 0.5, 1.0), roughness=0.6, metallic=0.2), sg.Material(color=(1, 1, 1, 1), emission=(1.0, 0.9, 0.8), emissive_strength=9.0, roughness=1.0, metallic=0.0)]
+    ids = np.zeros(n_tris, dtype=np.uint32)
+    ids[-1] = 1
+    tang = np.tile(np.array([1, 0, 0], dtype=np.float32), (n_tris, 3, 1))
+    return sg.Scene(positions=pos, normals=None, texcoords=rng.uniform(0, 1, size=(n_tris, 3, 2)).astype(np.float32), tangents=tang, material_ids=ids,
+                    materials=mats, textures=[], camera=sg.look_camera((0.0, 0.0, 0.0), yaw_deg=0.0, yfov=0.9, aspect=32 / 24))
+
+
+@pytest.mark.parametrize("n_tris", [1, 2, 3, 5, 9])
+def test_tiny_scenes_root_leaf(gpu, oracle, sg, n_tris):
+    """Scenes so small that a BVH root is itself a leaf (bvh.h:336-346) or the tree is one or two levels deep, with one
+    emissive triangle: the wavefront kernel starts on a leaf reference and the light BVH is a single leaf."""
+    g = _cmp_render(gpu, oracle, _tiny_scene(sg, n_tris, 100 + n_tris), W=32, H=24, SPP=4)
+    assert (g != 1.0).any()  # something was hit
+
+
+def test_degenerate_triangles(gpu, oracle, sg):
+    """Zero-area triangles (two equal vertices, three collinear vertices, all three equal) and needle-thin ones: the
+    reference divides by a zero determinant / normalises a zero normal for them; whatever NaN or infinity that produces
+    must come out the same way on the GPU (hits, counters, framebuffer after sanitize_nans)."""
+    sc = sg.room_scene(500, seed=77, n_lights=3, n_materials=6, tex_size=8, n_tex_sets=2)
+    pos = sc.positions.copy()
+    rng = np.random.default_rng(5)
+    idx = rng.choice(np.arange(12, 500), size=60, replace=False)  # keep the room walls and lights intact
+    for n, t in enumerate(idx):
+        kind = n % 4
+        if kind == 0:
+            pos[t, 1] = pos[t, 0]  # two equal vertices
+        elif kind == 1:
+            pos[t, 2] = pos[t, 0] + (pos[t, 1] - pos[t, 0]) * np.float32(0.25)  # collinear (up to rounding)
+        elif kind == 2:
+            pos[t, 1] = pos[t, 0]
+            pos[t, 2] = pos[t, 0]  # a point
+        else:
+            pos[t, 2] = pos[t, 1] + np.float32(1e-7) * (pos[t, 2] - pos[t, 1])  # needle
+    sc.positions = pos
+    _cmp_render(gpu, oracle, sc, W=48, H=40, SPP=6)
+
+
 def test_texture_views_mixed_sizes_and_sharing(gpu, oracle, sg):
     """rt_create stores texels tiled and interleaves the equally sized textures of a material (DevTexture views); the
     sampled values must not notice: odd sizes that are no multiple of a tile, a material whose slots differ in size,
