@@ -143,6 +143,7 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()  # RT_FLAG_DEVICE_FB precondition (rt_abi.h): the zero-fills above ran on torch's stream
     for _ in range(args.warmup):
         step()
     sync()

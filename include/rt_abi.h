@@ -129,7 +129,11 @@ typedef struct rt_params {
 
 enum {
     RT_FLAG_NONE = 0,
-    RT_FLAG_DEVICE_FB = 1, /* fb_rgb is a device pointer (HBM resident); no D2H copy */
+    RT_FLAG_DEVICE_FB = 1, /* fb_rgb is a device pointer (HBM resident); no D2H copy. The library writes it on the scene's
+                              own non-blocking stream and synchronises that stream before returning, so results are
+                              complete on return; PRECONDITION: the buffer must be idle on entry (the caller has
+                              synchronised whatever stream last touched it, e.g. its allocation's zero-fill) — the
+                              library's stream is not ordered with any caller stream. */
     RT_FLAG_COUNTERS = 2,  /* run the instrumented kernel variant and fill the event counters of rt_stats
                               (slower; timing fields are filled whenever `stats` is non-NULL) */
     RT_FLAG_MEGAKERNEL = 4 /* RT_RNG_DEVICE only: use the persistent one-lane-per-pixel megakernel instead of the

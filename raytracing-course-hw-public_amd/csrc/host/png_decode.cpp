@@ -77,6 +77,10 @@ extern "C" int rt_png_decode_file(const char *path, uint32_t *w_out, uint32_t *h
     }
     if (!seen_ihdr || w == 0 || h == 0)
         return rt::fail(RT_ERR_FORMAT, "PNG: missing IHDR");
+    // stb_image caps both dimensions at 1 << 24 (STBI_MAX_DIMENSIONS) and rejects images whose byte count overflows; the
+    // sizes below are computed in 64 bits and bounded before anything is allocated or indexed
+    if (w > (1u << 24) || h > (1u << 24) || (uint64_t)w * h > (1ull << 28))
+        return rt::fail(RT_ERR_FORMAT, "PNG: image too large (limit 2^24 per side, 2^28 pixels)");
     if (depth != 8 || interlace != 0)
         return rt::fail(RT_ERR_FORMAT, "PNG: only 8-bit non-interlaced images are supported");
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;

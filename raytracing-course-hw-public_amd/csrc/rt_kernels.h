@@ -7,14 +7,36 @@
 #include "rt_device_types.h"
 
 namespace rt {
+// HIP events for per-launch timing, created once per scene and reused by every render (no create/destroy inside the
+// timed region). next() returns nullptr when an event cannot be created; pairs are taken in (start, stop) order.
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    hipEvent_t next() {
+        if (used == ev.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess)
+                return nullptr;
+            ev.push_back(e);
+        }
+        return ev[used++];
+    }
+    void reset() { used = 0; }
+    void destroy() {
+        for (hipEvent_t e : ev)
+            (void)hipEventDestroy(e);
+        ev.clear();
+        used = 0;
+    }
+};
 // rt_kernels.hip: persistent megakernel (reference-RNG parity mode; cross-check of the wavefront path) + probes
 hipError_t launch_render(const DevScene &S, const RenderLaunch &L, bool stats, int blocks, hipStream_t stream);
 hipError_t launch_cast(const DevScene &S, const float *rays, uint32_t n, uint32_t *prim, float *bct, hipStream_t stream);
 hipError_t launch_light_pdf(const DevScene &S, const float *rays, uint32_t n, float *pdf, hipStream_t stream);
 // rt_wavefront.hip: one pass (pixel tile x sample range) of the wavefront pipeline, stream-ordered
-// `extend_events` (optional): receives one (start, stop) event pair per wf_extend launch, recorded on `stream`
+// `extend_events` (optional): one (start, stop) event pair per wf_extend launch is taken from the pool and recorded on `stream`
 hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int num_cus, bool first_pass, bool last_pass, hipStream_t stream,
-                                 std::vector<hipEvent_t> *extend_events);
+                                 EventPool *extend_events);
 // bytes of temporary storage rocPRIM's radix sort needs for `n` (key, slot) pairs
 size_t wavefront_sort_temp_bytes(size_t n);
 } // namespace rt

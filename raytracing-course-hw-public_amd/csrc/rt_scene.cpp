@@ -70,6 +70,7 @@ struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    rt::EventPool ext_events; // (start, stop) per wf_extend launch of the current render; reused by every render
     DevScene dev{};
     rt_camera cam{};
     std::vector<void *> owned;
@@ -187,6 +188,7 @@ struct rt_scene {
             (void)hipFree(d_rgb8);
         if (d_film_table)
             (void)hipFree(d_film_table);
+        ext_events.destroy();
         if (ev0)
             (void)hipEventDestroy(ev0);
         if (ev1)
@@ -539,7 +541,10 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
     if (blocks < 1)
         blocks = 1;
     const bool wavefront = p->rng_mode == RT_RNG_DEVICE && !(p->flags & RT_FLAG_MEGAKERNEL);
-    std::vector<hipEvent_t> extend_events; // (start, stop) per wf_extend launch
+    s->ext_events.reset();
+    // everything from here to the final synchronisation is queued on the scene's stream; a failure in between must not
+    // return while kernels are still in flight (a later ensure_wavefront / rt_destroy would free memory under them)
+    auto queue_render = [&]() -> int {
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (L.n_items > 0 && wavefront) {
         // ---- production path: wavefront pipeline over (pixel tile) x (sample range) passes, all stream-ordered
@@ -606,7 +611,7 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
                 W.pass_samples = std::min<uint32_t>(pass_spp, p->samples - s0);
                 W.n_paths = W.pass_pixels * W.pass_samples;
                 HIP_TRY(rt::launch_wavefront_pass(s->dev, W, counters, s->num_cus, s0 == 0, s0 + W.pass_samples >= p->samples, s->stream,
-                                                  stats ? &extend_events : nullptr));
+                                                  stats ? &s->ext_events : nullptr));
             }
         }
     } else if (L.n_items > 0) {
@@ -616,6 +621,12 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
     if (rgb8_out && L.n_items > 0) // film on the device: this shard's pixels -> rgb8 (image.h:49-82)
         HIP_TRY(rt::launch_film(d_fb, d_rgb8, n_pix, L.shard_index, L.shard_count, block, s->d_film_table, s->stream));
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    return RT_OK;
+    };
+    if (int rc = queue_render(); rc != RT_OK) {
+        (void)hipStreamSynchronize(s->stream);
+        return rc;
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
@@ -633,13 +644,6 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
             }
         }
     }
-    struct EventCleanup {
-        std::vector<hipEvent_t> &v;
-        ~EventCleanup() {
-            for (hipEvent_t e : v)
-                (void)hipEventDestroy(e);
-        }
-    } event_cleanup{extend_events};
     if (stats) {
         DevStats h{};
         if (counters)
@@ -657,11 +661,13 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
         stats->light_hits = h.lhits;
         stats->texel_fetches = h.texels;
         stats->kernel_ms = ms;
-        stats->dominant_launches = wavefront ? (uint32_t)(extend_events.size() / 2) : (L.n_items > 0 ? 1u : 0u);
+        const std::vector<hipEvent_t> &xe = s->ext_events.ev;
+        const size_t n_xe = s->ext_events.used & ~size_t(1);
+        stats->dominant_launches = wavefront ? (uint32_t)(n_xe / 2) : (L.n_items > 0 ? 1u : 0u);
         stats->dominant_ms = wavefront ? 0.0 : ms;
-        for (size_t i = 0; i + 1 < extend_events.size(); i += 2) {
+        for (size_t i = 0; i + 1 < n_xe; i += 2) {
             float t = 0;
-            if (hipEventElapsedTime(&t, extend_events[i], extend_events[i + 1]) == hipSuccess)
+            if (hipEventElapsedTime(&t, xe[i], xe[i + 1]) == hipSuccess)
                 stats->dominant_ms += t;
         }
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();

@@ -437,17 +437,25 @@ namespace rt {
 
 // One pass of the pipeline, fully stream-ordered (no host synchronisation): generate, ray_depth x (extend, shade,
 // advance), resolve. `L.rays_in/rays_out` are swapped locally per bounce.
+// every launch is checked: a failed launch (bad configuration, lost device) must not turn into a silently wrong image
+#define WF_LAUNCH(...)                                  \
+    do {                                                \
+        hipLaunchKernelGGL(__VA_ARGS__);                \
+        if (hipError_t le_ = hipGetLastError(); le_ != hipSuccess) \
+            return le_;                                 \
+    } while (0)
+
 hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int num_cus, bool first_pass, bool last_pass, hipStream_t stream,
-                                 std::vector<hipEvent_t> *extend_events) {
+                                 EventPool *extend_events) {
     const int gen_blocks = (int)((L.n_paths + 255u) / 256u < (uint32_t)num_cus * 16u ? (L.n_paths + 255u) / 256u : (uint32_t)num_cus * 16u);
     const dim3 block(256);
     hipError_t e = hipMemsetAsync(L.counters, 0, sizeof(uint32_t) * WF_CNT_WORDS, stream);
     if (e != hipSuccess)
         return e;
     if (stats)
-        hipLaunchKernelGGL((wf_generate<true>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
+        WF_LAUNCH((wf_generate<true>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
     else
-        hipLaunchKernelGGL((wf_generate<false>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
+        WF_LAUNCH((wf_generate<false>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
     const int ext_blocks = num_cus * 8;
     const int shade_blocks = num_cus * 8;
     uint32_t *h_count = L.host_count; // pinned word owned by the scene: per-bounce queue size read-back
@@ -455,14 +463,16 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
     for (uint32_t b = 0; b < L.ray_depth; ++b) {
         L.order = nullptr;
         if (b > 0 && L.sort_keys[0] && h_count) { // primary rays are coherent as generated
-            if (hipMemcpyAsync(h_count, L.counters + WF_CNT_IN, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
-                return hipGetLastError();
+            if ((e = hipMemcpyAsync(h_count, L.counters + WF_CNT_IN, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+                return e;
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess)
+                return e;
             n_active = *h_count;
             if (n_active == 0)
                 break;
             if (n_active >= 4096u) {
                 const uint32_t kb = (n_active + 255u) / 256u < (uint32_t)num_cus * 16u ? (n_active + 255u) / 256u : (uint32_t)num_cus * 16u;
-                hipLaunchKernelGGL(wf_sort_keys, dim3(kb), block, 0, stream, S, L, n_active);
+                WF_LAUNCH(wf_sort_keys, dim3(kb), block, 0, stream, S, L, n_active);
                 size_t tmp = L.sort_temp_bytes;
                 hipError_t se = rocprim::radix_sort_pairs(L.sort_temp, tmp, L.sort_keys[0], L.sort_keys[1], L.sort_vals[0], L.sort_vals[1], (size_t)n_active, 0u, 21u, stream);
                 if (se != hipSuccess)
@@ -470,27 +480,23 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
                 L.order = L.sort_vals[1];
             }
         }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (extend_events) { // time the dominant kernel per launch (bench.py roofline), HIP events on the launch stream
-            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-                extend_events->push_back(e0);
-                extend_events->push_back(e1);
-                (void)hipEventRecord(e0, stream);
-            } else {
-                e0 = e1 = nullptr;
-            }
-        }
+        // time the dominant kernel per launch (bench.py roofline): HIP events on the launch stream, taken from the scene's
+        // pool (created once, reused by every render)
+        hipEvent_t e0 = extend_events ? extend_events->next() : nullptr;
+        hipEvent_t e1 = e0 ? extend_events->next() : nullptr;
+        if (e0 && e1)
+            (void)hipEventRecord(e0, stream);
         if (stats)
-            hipLaunchKernelGGL((wf_extend<true>), dim3(ext_blocks), block, 0, stream, S, L);
+            WF_LAUNCH((wf_extend<true>), dim3(ext_blocks), block, 0, stream, S, L);
         else
-            hipLaunchKernelGGL((wf_extend<false>), dim3(ext_blocks), block, 0, stream, S, L);
-        if (e1)
+            WF_LAUNCH((wf_extend<false>), dim3(ext_blocks), block, 0, stream, S, L);
+        if (e0 && e1)
             (void)hipEventRecord(e1, stream);
         if (stats)
-            hipLaunchKernelGGL((wf_shade<true>), dim3(shade_blocks), block, 0, stream, S, L);
+            WF_LAUNCH((wf_shade<true>), dim3(shade_blocks), block, 0, stream, S, L);
         else
-            hipLaunchKernelGGL((wf_shade<false>), dim3(shade_blocks), block, 0, stream, S, L);
-        hipLaunchKernelGGL(wf_advance, dim3(1), dim3(64), 0, stream, L.counters);
+            WF_LAUNCH((wf_shade<false>), dim3(shade_blocks), block, 0, stream, S, L);
+        WF_LAUNCH(wf_advance, dim3(1), dim3(64), 0, stream, L.counters);
         WfRay *t = L.rays_in;
         L.rays_in = L.rays_out;
         L.rays_out = t;
@@ -499,8 +505,8 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         L.rng_out = tr;
     }
     const int res_blocks = (int)((L.pass_pixels + 255u) / 256u);
-    hipLaunchKernelGGL(wf_resolve, dim3(res_blocks > 0 ? res_blocks : 1), block, 0, stream, L, first_pass ? 1 : 0, last_pass ? 1 : 0);
-    return hipGetLastError();
+    WF_LAUNCH(wf_resolve, dim3(res_blocks > 0 ? res_blocks : 1), block, 0, stream, L, first_pass ? 1 : 0, last_pass ? 1 : 0);
+    return hipSuccess;
 }
 
 size_t wavefront_sort_temp_bytes(size_t n) {

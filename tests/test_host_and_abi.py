@@ -229,3 +229,34 @@ def test_loader_errors_are_codes_not_crashes(rt, tmp_path):
     assert "material" in str(e.value)
     with pytest.raises(rt.RtError):
         rt.png_decode(str(bad))
+
+
+def test_png_decoder_rejects_malformed_headers(rt, tmp_path):
+    """Untrusted IHDR fields: dimensions whose byte count would wrap size_t, zero sizes, truncated streams, bad filter
+    bytes and short IDAT data must come back as RT_ERR_FORMAT, never as an out-of-bounds access."""
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    def png(w, h, depth=8, ctype=6, interlace=0, raw=b"\x00" * 64, cut=None):
+        blob = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+        return blob if cut is None else blob[:cut]
+
+    cases = {
+        "huge_w": png(0xFFFFFFFF, 2),
+        "huge_h": png(2, 0xFFFFFFFF),
+        "wrap": png(0x40000001, 0x40000001),  # (stride + 1) * h wraps 64-bit size_t with 4 channels
+        "big_product": png(1 << 20, 1 << 20),
+        "zero_w": png(0, 4),
+        "short_idat": png(4, 4, raw=b"\x00" * 10),
+        "bad_filter": png(2, 2, raw=b"\x07" + b"\x00" * 8 + b"\x00" + b"\x00" * 8),
+        "bad_ctype": png(2, 2, ctype=5),
+        "truncated": png(4, 4, raw=b"\x00" * 68, cut=40),
+        "not_png": b"JFIF" * 20,
+    }
+    for name, blob in cases.items():
+        p = tmp_path / (name + ".png")
+        p.write_bytes(blob)
+        with pytest.raises(rt.RtError) as e:
+            rt.png_decode(str(p))
+        assert e.value.code == 6, name  # RT_ERR_FORMAT

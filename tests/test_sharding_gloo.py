@@ -30,11 +30,17 @@ def _worker(rank, world, port, out_path, mode):
     sc = rt.scenegen.boxes_scene(n_boxes=6, seed=31, n_lights=2)
     orc = oracle.OracleScene(sc)
     n_pix = W * H
-    fb = np.zeros((H, W, 3), dtype=np.float32)
+    fb = np.full((H, W, 3), -1.0, dtype=np.float32)  # radiance is never negative: -1 marks 'not written'
     orc.run_raytracer(W, H, SPP, seed=77, shard_index=rank, shard_count=world, shard_block=BLOCK, out=fb, threads=2)
     g = sharding.FramebufferGather(n_pix, BLOCK, rank, world, torch.device("cpu"))
     full = g.gather(torch.from_numpy(fb.reshape(-1)))
-    assert sharding.shard_pixels(n_pix, BLOCK, rank, world) == int((fb.reshape(-1, 3) != 0).any(axis=1).sum()) or True
+    # exactly this rank's interleaved blocks were written
+    mine = np.zeros(n_pix, dtype=bool)
+    for b0 in range(rank * BLOCK, n_pix, world * BLOCK):
+        mine[b0 : b0 + BLOCK] = True
+    written = (fb.reshape(-1, 3) != -1.0).any(axis=1)
+    assert sharding.shard_pixels(n_pix, BLOCK, rank, world) == int(mine.sum())
+    assert not written[~mine].any() and written[mine].all()
     # the rgb8 flow bench.py runs by default (film applied per rank, uint8 slabs gathered: a 4x smaller message)
     img = oracle.tonemap(fb)
     g8 = sharding.FramebufferGather(n_pix, BLOCK, rank, world, torch.device("cpu"), dtype=torch.uint8)
