@@ -41,8 +41,9 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u /* 2: rt_scene_desc carries analytic primitives (scene-txt front end) */
 #define RT_TEX_NONE (-1)
+#define RT_ALL_DEVICES (-1) /* rt_create: one scene replica on every visible GPU + an RCCL communicator over them */
 
 /* error codes */
 enum {
@@ -94,6 +95,20 @@ typedef struct rt_material_desc {
     int32_t normal_tex;
 } rt_material_desc;
 
+/* Analytic primitives of the scene-txt front end (BASELINE configs 1-2; sample_data scene files: "ELLIPSOID rx ry rz", "PLANE nx ny nz"
+ * with POSITION / ROTATION x y z w). The reference at HEAD renders triangles only (geometry.h:505) and keeps just an unused
+ * intersect_ray_sphere (raytracer.h:61-77), so their semantics are DEFINED here (include/rt_primspec.h) and shared by the
+ * HIP kernels and the CPU oracle: "parity unpinned" against the reference, bit-exact between the two. BOX and TRIANGLE
+ * primitives are turned into triangles by the loader and take the (pinned) triangle path. */
+enum { RT_PRIM_ELLIPSOID = 1, RT_PRIM_PLANE = 2 };
+typedef struct rt_primitive_desc {
+    uint32_t kind;        /* RT_PRIM_* */
+    uint32_t material_id; /* into rt_scene_desc.materials; its textures are not sampled (scene-txt materials have none) */
+    float param[3];       /* ELLIPSOID: semi-axes; PLANE: normal (need not be unit length) */
+    float position[3];
+    float rotation[4];    /* quaternion x y z w (order of sample_data and of geometry.h:154-156) */
+} rt_primitive_desc;
+
 typedef struct rt_scene_desc {
     uint32_t abi_version; /* RT_ABI_VERSION */
     uint32_t n_triangles;
@@ -109,7 +124,10 @@ typedef struct rt_scene_desc {
     rt_camera camera;
     float bg_color[3];
     uint32_t ray_depth; /* Scene::ray_depth; 8 for glTF (scene.h:186, config.h:17) */
+    uint32_t n_primitives; /* analytic primitives, tested by brute force next to the BVH (at most RT_MAX_PRIMITIVES) */
+    const rt_primitive_desc *primitives;
 } rt_scene_desc;
+#define RT_MAX_PRIMITIVES 4096u
 
 typedef struct rt_params {
     uint32_t width;
@@ -172,14 +190,31 @@ typedef struct rt_scene rt_scene; /* opaque: device-resident scene + both BVHs *
 int rt_create(const rt_scene_desc *desc, int device, rt_scene **out);
 void rt_destroy(rt_scene *scene);
 
+/* Multi-GPU scenes (replaces the reference's thread pool over spans, raytracer.h:636-665, at node scale).
+ * rt_create(desc, RT_ALL_DEVICES, &s) — or rt_create_on(desc, devices, n, &s) for an explicit list of HIP ordinals —
+ * builds one replica of the scene per GPU (one host thread each) and ONE RCCL communicator over them (ncclCommInitAll),
+ * inside this call. rt_render / rt_render_rgb8 on such a scene split the image into interleaved pixel blocks
+ * (block b -> GPU b % G; 8 image rows per block unless rt_params.shard_block says otherwise; rt_params.shard_count must
+ * be 0 or 1), render them concurrently and gather every GPU's blocks on the first GPU with grouped ncclSend/ncclRecv
+ * (rgb8 with the device film: 3 B/pixel), then deliver the whole image to the caller's buffer (host memory, or memory of
+ * the first GPU with RT_FLAG_DEVICE_FB). The image is bit-identical to a single-GPU render (per-(pixel, sample) seeding).
+ * The probe entry points (rt_cast_rays, rt_light_pdf, rt_bvh_info, rt_film_rgb8) run on the first GPU's replica.
+ * Errors: RT_ERR_COMM when RCCL cannot be loaded, refuses the device set, or an exchange fails.
+ * Environment (tests): RT_GROUP_TRANSPORT=copy replaces the RCCL exchange by peer copies (lets a one-GPU box rehearse
+ * G > 1 with repeated ordinals, which RCCL refuses); RT_GROUP_SELF_EXCHANGE=1 also sends the first GPU's own blocks
+ * through ncclSend/ncclRecv (exercises the RCCL path with G = 1). */
+int rt_create_on(const rt_scene_desc *desc, const int *devices, int n_devices, rt_scene **out);
+int rt_scene_device_count(const rt_scene *scene); /* GPUs rendering for this scene (1 for rt_create on one device) */
+
 /* Replaces run_raytracer(scene, image) (raytracer.h:629-674). Blocking. fb_rgb: width*height*3 floats,
  * row-major, y down, linear radiance = render_pixel(ctx,x,y) (raytracer.h:618-627). ray_depth == 0 is a
  * silent no-op like raytracer.h:630-631. `stats` may be NULL. */
 int rt_render(rt_scene *scene, const rt_params *params, float *fb_rgb, rt_stats *stats);
 
 /* Closest-hit probe: cast `n` rays through the scene BVH exactly as cast_ray (raytracer.h:540-553) with
- * min_dst = EPS. rays: 6*n floats (origin, dir). Outputs per ray: prim (original triangle index or
- * 0xFFFFFFFF), and bct[3] = (b, c, t) of bvh.h:83-85. Used by the parity tests for bit-exact hit indices. */
+ * min_dst = EPS. rays: 6*n floats (origin, dir). Outputs per ray: prim (original triangle index; n_triangles + i for
+ * analytic primitive i; 0xFFFFFFFF for a miss), and bct[3] = (b, c, t) of bvh.h:83-85 ((0, 0, t) for an analytic
+ * primitive). Used by the parity tests for bit-exact hit indices. */
 int rt_cast_rays(rt_scene *scene, const float *rays, uint32_t n, uint32_t *prim_out, float *bct_out);
 
 /* Light-pdf probe: bvh_mix_dist::pdf (raytracer.h:363-375) for n (origin, dir) pairs. */

@@ -20,6 +20,15 @@ typedef struct rt_loaded_scene rt_loaded_scene; /* owns the arrays an rt_scene_d
  * KHR_materials_emissive_strength. Quirks of the reference loader are kept (see DESIGN.md "loader quirks").
  * Also sets bg_color = ENV_MAP_INTENSITY (main.cpp:28) and ray_depth = DEFAULT_RAY_DEPTH (scene.h:186). */
 int rt_gltf_load(const char *path, float aspect, rt_loaded_scene **out);
+/* The scene-txt front end (BASELINE configs 1-2: sample_data scene files; no reference implementation at HEAD, grammar and
+ * semantics in csrc/host/txt_loader.cpp): BOX and TRIANGLE primitives become triangles, ELLIPSOID and PLANE become
+ * rt_primitive_desc entries, COLOR / EMISSION / METALLIC / DIELECTRIC / IOR become materials, legacy point / directional
+ * lights are parsed and ignored. rt_scene_load picks the loader by file extension (".txt" -> scene-txt, else glTF): it is
+ * what the CLI calls. rt_loaded_info returns what a scene-txt file says about the image (DIMENSIONS, SAMPLES; 0 for glTF)
+ * and how many NEW_LIGHT blocks were ignored. */
+int rt_txt_load(const char *path, rt_loaded_scene **out);
+int rt_scene_load(const char *path, float aspect, rt_loaded_scene **out);
+int rt_loaded_info(const rt_loaded_scene *s, uint32_t *width, uint32_t *height, uint32_t *samples, uint32_t *ignored_lights);
 const rt_scene_desc *rt_loaded_desc(const rt_loaded_scene *s);
 void rt_loaded_free(rt_loaded_scene *s);
 

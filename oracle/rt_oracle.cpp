@@ -23,11 +23,13 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
 #include "../include/rt_abi.h"
 #include "../include/rt_devspec.h"
+#include "../include/rt_primspec.h"
 
 namespace {
 
@@ -380,6 +382,43 @@ struct BVH {
         nodes[idx].right = r;
         return idx;
     }
+    // The same build for big inputs (10^7 triangles: minutes single-threaded): the two subtrees of a node are independent
+    // once split_node has partitioned the index range, so the top levels build them concurrently into vectors of their
+    // own and splice them in the reference's pre-order numbering (node, left subtree, right subtree: bvh.h:351-363).
+    // Node for node the work is build_node's; the result is identical (tests/test_oracle_golden.py compares both paths).
+    static void build_node_parallel(const std::vector<Object> &all, std::vector<BVHNode> &nodes, uint32_t offset, uint32_t *objs, size_t n,
+                                    const Aabb &box, uint32_t min_node_size, uint32_t max_depth, int par_levels) {
+        std::vector<float> t1, t2;
+        if (par_levels <= 0 || n < 65536 || max_depth == 0) {
+            build_node(all, nodes, offset, objs, n, box, min_node_size, max_depth, t1, t2);
+            return;
+        }
+        size_t mid = split_node(all, objs, n, box, t1, t2);
+        size_t nl = mid, nr = n - mid;
+        if (nl == 0 || nr == 0 || (nl < min_node_size && nr < min_node_size)) {
+            nodes.push_back({box, NO_CHILD, NO_CHILD, offset, (uint32_t)(offset + n)});
+            return;
+        }
+        std::vector<BVHNode> ln, rn;
+        std::thread left([&] {
+            build_node_parallel(all, ln, offset, objs, nl, bounding_box_of(all, objs, nl), min_node_size, max_depth - 1, par_levels - 1);
+        });
+        build_node_parallel(all, rn, offset + nl, objs + nl, nr, bounding_box_of(all, objs + nl, nr), min_node_size, max_depth - 1, par_levels - 1);
+        left.join();
+        const uint32_t idx = nodes.size(); // sub-vectors are numbered from 0 with their root first
+        const uint32_t lbase = idx + 1, rbase = lbase + (uint32_t)ln.size();
+        nodes.push_back({box, lbase, rbase, 0, 0});
+        for (auto *sub : {&ln, &rn}) {
+            const uint32_t base = sub == &ln ? lbase : rbase;
+            for (BVHNode nd : *sub) {
+                if (nd.left != NO_CHILD)
+                    nd.left += base;
+                if (nd.right != NO_CHILD)
+                    nd.right += base;
+                nodes.push_back(nd);
+            }
+        }
+    }
     // bvh.h:368-393
     template <class Pred> static BVH build(const std::vector<Object> &all, Pred &&pred) {
         BVH res;
@@ -392,8 +431,16 @@ struct BVH {
             if (pred(all[i]))
                 res.objects.push_back(i);
         std::vector<float> t1, t2;
-        res.root = build_node(all, res.nodes, 0, res.objects.data(), res.objects.size(),
-                              bounding_box_of(all, res.objects.data(), res.objects.size()), 4, 64, t1, t2);
+        const char *par = std::getenv("RTO_BUILD_PARALLEL_LEVELS"); // 0 forces the plain recursive build_node
+        const int par_levels = par ? std::atoi(par) : 4;
+        if (par_levels > 0 && res.objects.size() >= 65536) {
+            build_node_parallel(all, res.nodes, 0, res.objects.data(), res.objects.size(),
+                                bounding_box_of(all, res.objects.data(), res.objects.size()), 4, 64, par_levels);
+            res.root = 0;
+        } else {
+            res.root = build_node(all, res.nodes, 0, res.objects.data(), res.objects.size(),
+                                  bounding_box_of(all, res.objects.data(), res.objects.size()), 4, 64, t1, t2);
+        }
         return res;
     }
 };
@@ -421,6 +468,9 @@ struct rto_scene {
     V3 bg_color;
     unsigned ray_depth;
     BVH scene_bvh, light_bvh;
+    // analytic primitives of the scene-txt front end (no reference implementation at HEAD: semantics defined by
+    // include/rt_primspec.h, shared with the HIP kernels; "parity unpinned")
+    std::vector<rt_primitive_desc> prims;
 };
 
 namespace {
@@ -649,12 +699,33 @@ template <class R> struct Integrator {
         return res;
     }
 
-    // raytracer.h:540-553 + bvh.h:170-180
+    // raytracer.h:540-553 + bvh.h:170-180; then the analytic primitives, brute force in index order with the strict-less
+    // replacement of update_intersection (bvh.h:132)
     bool cast_ray(const Ray &ray, IntersectionInfo &out) {
         c.casts++;
-        if (sc.scene_bvh.root == NO_CHILD)
-            return false;
-        Hit h = sc.scene_bvh.intersect_ray(ray, EPS, sc.scene_bvh.root, c);
+        Hit h;
+        if (sc.scene_bvh.root != NO_CHILD)
+            h = sc.scene_bvh.intersect_ray(ray, EPS, sc.scene_bvh.root, c);
+        int prim = -1;
+        float prim_t = 0;
+        float prim_n[3] = {0, 0, 1};
+        const float oo[3] = {ray.start.x, ray.start.y, ray.start.z}, dd[3] = {ray.dir.x, ray.dir.y, ray.dir.z};
+        for (size_t i = 0; i < sc.prims.size(); ++i) {
+            float t, n[3];
+            const float best_t = prim >= 0 ? prim_t : h.xs.z;
+            if (rt_prim_intersect(&sc.prims[i], oo, dd, EPS, &t, n) && ((prim < 0 && !h.has) || best_t > t)) {
+                prim = (int)i;
+                prim_t = t;
+                prim_n[0] = n[0], prim_n[1] = n[1], prim_n[2] = n[2];
+            }
+        }
+        if (prim >= 0) {
+            const Material &mat = sc.materials[sc.prims[prim].material_id];
+            c.shaded++;
+            V3 n{prim_n[0], prim_n[1], prim_n[2]};
+            out = {n, n, prim_t, (uint32_t)(sc.objects.size() + prim), false, mat.color, mat.emission, mat.metallic, mat.roughness, mat.ior};
+            return true;
+        }
         if (!h.has)
             return false;
         out = to_intersection_info(sc, h, ray, c);
@@ -824,6 +895,14 @@ int rto_create(const rt_scene_desc *d, rto_scene **out) {
             return RT_ERR_INVALID_ARG;
         }
     }
+    if (d->n_primitives && d->primitives)
+        s->prims.assign(d->primitives, d->primitives + d->n_primitives);
+    for (const rt_primitive_desc &pr : s->prims)
+        if (pr.material_id >= d->n_materials) {
+            delete s;
+            g_err = "rto_create: primitive material id out of range";
+            return RT_ERR_INVALID_ARG;
+        }
     s->cam = d->camera;
     s->bg_color = {d->bg_color[0], d->bg_color[1], d->bg_color[2]};
     s->ray_depth = d->ray_depth;
@@ -892,6 +971,14 @@ int rto_cast_rays(rto_scene *s, const float *rays, uint32_t n, uint32_t *prim_ou
         bct_out[3 * i + 0] = h.has ? h.xs.x : 0.0f;
         bct_out[3 * i + 1] = h.has ? h.xs.y : 0.0f;
         bct_out[3 * i + 2] = h.has ? h.xs.z : 0.0f;
+        for (size_t k = 0; k < s->prims.size(); ++k) { // analytic primitives: index n_triangles + k, (0, 0, t)
+            float t, nn[3];
+            if (rt_prim_intersect(&s->prims[k], &rays[6 * i], &rays[6 * i + 3], EPS, &t, nn) && (prim_out[i] == NO_CHILD || bct_out[3 * i + 2] > t)) {
+                prim_out[i] = (uint32_t)(s->objects.size() + k);
+                bct_out[3 * i + 0] = bct_out[3 * i + 1] = 0.0f;
+                bct_out[3 * i + 2] = t;
+            }
+        }
     }
     return RT_OK;
 }

@@ -39,6 +39,7 @@ from ._ctypes_abi import (
     u32ptr,
 )
 
+RT_ALL_DEVICES = -1
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "csrc", "librt_amd.so")  # RT_AMD_LIB: tuning variants only
 _lib: Optional[C.CDLL] = None
@@ -81,6 +82,12 @@ class LoadedScene:
     def arrays(self) -> dict:
         return desc_to_arrays(self.desc)
 
+    def info(self) -> dict:
+        """DIMENSIONS / SAMPLES of a scene-txt file (0 for glTF) and the number of ignored NEW_LIGHT blocks."""
+        w, h, s, l = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib().rt_loaded_info(self._h, C.byref(w), C.byref(h), C.byref(s), C.byref(l)))
+        return {"width": w.value, "height": h.value, "samples": s.value, "ignored_lights": l.value}
+
     def close(self) -> None:
         if self._h:
             lib().rt_loaded_free(self._h)
@@ -99,6 +106,20 @@ def parse_gltf_scene(path: str, aspect: float) -> LoadedScene:
     return LoadedScene(h)
 
 
+def parse_scene_txt(path: str) -> LoadedScene:
+    """The scene-txt front end (csrc/host/txt_loader.cpp): sample_data-style scene files -> triangles + analytic primitives."""
+    h = C.c_void_p()
+    _check(lib().rt_txt_load(os.fsencode(path), C.byref(h)))
+    return LoadedScene(h)
+
+
+def load_scene(path: str, aspect: float) -> LoadedScene:
+    """What the CLI does: scene-txt for *.txt, glTF otherwise (rt_scene_load)."""
+    h = C.c_void_p()
+    _check(lib().rt_scene_load(os.fsencode(path), C.c_float(aspect), C.byref(h)))
+    return LoadedScene(h)
+
+
 def _as_desc(scene) -> Tuple[RtSceneDesc, object]:
     if isinstance(scene, LoadedScene):
         return scene.desc, scene
@@ -111,11 +132,21 @@ def _as_desc(scene) -> Tuple[RtSceneDesc, object]:
 class DeviceScene:
     """Device-resident scene + both BVHs: the RaytracerStaticContext of raytracer.h:434-455, in HBM."""
 
-    def __init__(self, scene, device: int = 0):
+    def __init__(self, scene, device=0):
+        """`device`: a HIP ordinal; RT_ALL_DEVICES (-1) for one replica per visible GPU + an RCCL communicator; or a list
+        of ordinals (rt_create_on). Multi-GPU scenes shard every render over their GPUs and gather on the first one."""
         desc, keep = _as_desc(scene)
         self._keep = keep
         self._h = C.c_void_p()
-        _check(lib().rt_create(C.byref(desc), int(device), C.byref(self._h)))
+        if isinstance(device, (list, tuple)):
+            devs = (C.c_int * len(device))(*[int(d) for d in device])
+            _check(lib().rt_create_on(C.byref(desc), devs, len(device), C.byref(self._h)))
+        else:
+            _check(lib().rt_create(C.byref(desc), int(device), C.byref(self._h)))
+
+    @property
+    def n_devices(self) -> int:
+        return int(lib().rt_scene_device_count(self._h))
 
     def close(self) -> None:
         if self._h:
@@ -264,12 +295,15 @@ def png_decode(path: str) -> np.ndarray:
 __all__ = [
     "DeviceScene",
     "LoadedScene",
+    "RT_ALL_DEVICES",
     "RT_RNG_DEVICE",
     "RT_RNG_REFERENCE",
     "RtError",
     "device_count",
     "lib",
     "parse_gltf_scene",
+    "parse_scene_txt",
+    "load_scene",
     "png_decode",
     "scenegen",
     "tonemap",

@@ -9,7 +9,9 @@ import ctypes as C
 
 import numpy as np
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
+RT_PRIM_ELLIPSOID = 1
+RT_PRIM_PLANE = 2
 RT_TEX_NONE = -1
 RT_RNG_DEVICE = 0
 RT_RNG_REFERENCE = 1
@@ -63,6 +65,16 @@ class RtMaterialDesc(C.Structure):
     ]
 
 
+class RtPrimitiveDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32),
+        ("material_id", C.c_uint32),
+        ("param", C.c_float * 3),
+        ("position", C.c_float * 3),
+        ("rotation", C.c_float * 4),
+    ]
+
+
 class RtSceneDesc(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32),
@@ -79,6 +91,8 @@ class RtSceneDesc(C.Structure):
         ("camera", RtCamera),
         ("bg_color", C.c_float * 3),
         ("ray_depth", C.c_uint32),
+        ("n_primitives", C.c_uint32),
+        ("primitives", C.POINTER(RtPrimitiveDesc)),
     ]
 
 
@@ -135,9 +149,14 @@ ABI_PROTOTYPES = {
     "rt_last_error": (C.c_char_p, []),
     "rt_abi_version": (C.c_uint32, []),
     "rt_device_count": (C.c_int, []),
+    "rt_create_on": (C.c_int, [C.POINTER(RtSceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "rt_scene_device_count": (C.c_int, [C.c_void_p]),
 }
 HOST_PROTOTYPES = {
     "rt_gltf_load": (C.c_int, [C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),
+    "rt_txt_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "rt_scene_load": (C.c_int, [C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),
+    "rt_loaded_info": (C.c_int, [C.c_void_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
     "rt_loaded_desc": (C.POINTER(RtSceneDesc), [C.c_void_p]),
     "rt_loaded_free": (None, [C.c_void_p]),
     "rt_write_ppm": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, c_u8_p]),
@@ -224,6 +243,18 @@ class DescHolder:
             d.bg_color[k] = np.float32(scene.bg_color[k])
         d.camera.fov_x = np.float32(cam.fov_x)
         d.ray_depth = scene.ray_depth
+        prims = list(getattr(scene, "primitives", None) or [])
+        self.primitives = (RtPrimitiveDesc * max(1, len(prims)))()
+        for i, pr in enumerate(prims):  # (kind, material_id, param[3], position[3], rotation xyzw[4])
+            q = self.primitives[i]
+            q.kind, q.material_id = int(pr["kind"]), int(pr["material_id"])
+            for k in range(3):
+                q.param[k] = np.float32(pr["param"][k])
+                q.position[k] = np.float32(pr["position"][k])
+            for k in range(4):
+                q.rotation[k] = np.float32(pr["rotation"][k])
+        d.n_primitives = len(prims)
+        d.primitives = self.primitives
         self.desc = d
 
 
@@ -253,6 +284,11 @@ def desc_to_arrays(desc: RtSceneDesc) -> dict:
         },
         "bg_color": np.array(list(desc.bg_color), dtype=np.float32),
         "ray_depth": int(desc.ray_depth),
+        "primitives": [
+            {"kind": int(desc.primitives[i].kind), "material_id": int(desc.primitives[i].material_id), "param": np.array(list(desc.primitives[i].param), dtype=np.float32),
+             "position": np.array(list(desc.primitives[i].position), dtype=np.float32), "rotation": np.array(list(desc.primitives[i].rotation), dtype=np.float32)}
+            for i in range(desc.n_primitives)
+        ],
     }
     for i in range(desc.n_materials):
         m = desc.materials[i]

@@ -26,6 +26,7 @@
 
 #include "../../../include/rt_host.h"
 #include "../rt_error.h"
+#include "loaded_scene.h"
 #include "mini_json.h"
 
 namespace {
@@ -113,19 +114,6 @@ struct FormatError : std::runtime_error {
 };
 
 } // namespace
-
-struct rt_loaded_scene {
-    rt_scene_desc desc{};
-    std::vector<float> positions, normals, texcoords, tangents;
-    std::vector<uint32_t> material_ids;
-    std::vector<rt_material_desc> materials;
-    std::vector<rt_texture_desc> textures;
-    std::vector<uint8_t *> texels;
-    ~rt_loaded_scene() {
-        for (auto *p : texels)
-            rt_free(p);
-    }
-};
 
 namespace {
 

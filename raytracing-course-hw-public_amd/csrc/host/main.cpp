@@ -1,8 +1,9 @@
-// main.cpp — host driver behind the reference's CLI:  run.sh <scene.gltf> <W> <H> <SPP> <out.ppm>
+// main.cpp — host driver behind the reference's CLI:  run.sh <scene.gltf | scene.txt> <W> <H> <SPP> <out.ppm>
 // Restates src/main.cpp:16-49: parse 5 positional arguments, load the scene, render, tone-map, write the PPM.
 // The only change of substance is line 37 of the reference: run_raytracer(scene, img) becomes
 // rt_create + rt_render_rgb8 through the C ABI (include/rt_abi.h): render and film (image.h) on the device.
-// Optional environment: RT_DEVICE (HIP ordinal, default 0), RT_RNG_MODE (device|reference), RT_SEED.
+// Optional environment: RT_DEVICE (HIP ordinal; unset = every visible GPU: replicas + RCCL gather inside the library, the
+// node-scale counterpart of the thread pool of raytracer.h:636-665), RT_RNG_MODE (device|reference), RT_SEED.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,11 +32,13 @@ int main(int argc, char **argv) {
         return EXIT_FAILURE;
     }
     rt_loaded_scene *loaded = nullptr;
-    if (rt_gltf_load(argv[1], static_cast<float>(width) / height, &loaded) != RT_OK)
+    // *.txt: the scene-txt front end (BASELINE configs 1-2; no parser at the reference's HEAD), anything else: glTF (main.cpp:27)
+    if (rt_scene_load(argv[1], static_cast<float>(width) / height, &loaded) != RT_OK)
         return die("load");
     const char *dev_env = std::getenv("RT_DEVICE");
     rt_scene *scene = nullptr;
-    if (rt_create(rt_loaded_desc(loaded), dev_env ? std::atoi(dev_env) : 0, &scene) != RT_OK) {
+    const int device = dev_env ? std::atoi(dev_env) : (rt_device_count() > 1 ? RT_ALL_DEVICES : 0);
+    if (rt_create(rt_loaded_desc(loaded), device, &scene) != RT_OK) {
         rt_loaded_free(loaded);
         return die("rt_create");
     }

@@ -11,6 +11,7 @@
 
 #include "../../include/rt_abi.h"
 #include "../../include/rt_devspec.h"
+#include "../../include/rt_primspec.h"
 #include "rt_device_types.h"
 
 namespace {
@@ -256,6 +257,31 @@ struct Hit {
     float b, c, t;
 };
 
+// Analytic primitives (scene-txt ELLIPSOID / PLANE, include/rt_primspec.h): tested by brute force AFTER the BVH, in index
+// order, with the same strict-less replacement as update_intersection (bvh.h:132) — the CPU oracle does exactly this.
+DEV rt_primitive_desc load_prim(const rt_primitive_desc *prims, uint32_t i) {
+    rt_primitive_desc p;
+    const uint4 *src = reinterpret_cast<const uint4 *>(prims + i); // 48-byte records, 16-byte aligned
+    uint4 *dst = reinterpret_cast<uint4 *>(&p);
+    dst[0] = src[0];
+    dst[1] = src[1];
+    dst[2] = src[2];
+    return p;
+}
+DEV void prims_closest(const DevScene &S, V3 o, V3 d, Hit &best) {
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    for (uint32_t i = 0; i < S.n_prims; ++i) {
+        const rt_primitive_desc p = load_prim(S.prims, i);
+        float t, n[3];
+        if (rt_prim_intersect(&p, oo, dd, 1e-4f /* EPS, config.h:15 */, &t, n) && (best.k == RT_NONE || best.t > t)) {
+            best.k = RT_PRIM_FLAG | i;
+            best.b = 0.0f;
+            best.c = 0.0f;
+            best.t = t;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- traversal stack
 // Deferred far siblings: {child ref, far entry distance, enclosing subtree's local best}. The first LDS_DEPTH
 // positions live in LDS, one column per thread (bank = thread % 32: conflict free whatever the lanes' depths);
@@ -279,6 +305,7 @@ template <int LDS_DEPTH> struct StackMemT {
             lds[(1 * LDS_DEPTH + sp) * 256] = __float_as_uint(d);
             lds[(2 * LDS_DEPTH + sp) * 256] = __float_as_uint(loc);
         } else {
+            DIAG(28, (unsigned long long)__popcll(__ballot(1)));
             ov_ref[sp - LDS_DEPTH] = ref;
             ov_d[sp - LDS_DEPTH] = d;
             ov_loc[sp - LDS_DEPTH] = loc;
@@ -503,6 +530,7 @@ template <bool STATS, class STK> DEV void trav_step_inner_fast(Trav &T, const De
 template <class STK> DEV void trav_pop_wave(Trav &T, STK &stk) {
     while (__ballot(T.cur == T_POP) != 0ull) {
         DIAG(7, 1);
+        DIAG(27, (unsigned long long)__popcll(__ballot(T.cur == T_POP)));
         const bool pop = T.cur == T_POP;
         const bool go = pop & (T.sp != 0);
         const int nsp = T.sp - 1;
@@ -663,7 +691,30 @@ struct Surf { // ray_intersection_info bvh.h:18-29
 
 // to_intersection_info bvh.h:80-121
 template <bool STATS>
-DEV Surf make_surf(const DevScene &S, const Hit &h, V3 rd, const float *s_lin, const float *s_gam, LaneStats<STATS> &st) {
+DEV Surf make_surf(const DevScene &S, const Hit &h, V3 ro, V3 rd, const float *s_lin, const float *s_gam, LaneStats<STATS> &st) {
+    if (h.k & RT_PRIM_FLAG) { // analytic primitive: geometric normal only, untextured material (rt_primspec.h)
+        const rt_primitive_desc p = load_prim(S.prims, h.k & ~RT_PRIM_FLAG);
+        const float oo[3] = {ro.x, ro.y, ro.z}, dd[3] = {rd.x, rd.y, rd.z};
+        float t, n[3] = {0.f, 0.f, 1.f};
+        (void)rt_prim_intersect(&p, oo, dd, 1e-4f, &t, n); // same inputs as the cast -> same root, same normal
+        DevMaterial m;
+        {
+            const float4 *mp = reinterpret_cast<const float4 *>(S.materials + p.material_id);
+            float4 *q = reinterpret_cast<float4 *>(&m);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                q[i] = mp[i];
+        }
+        st.shaded();
+        Surf s;
+        s.normal = s.shading_normal = mk(n[0], n[1], n[2]);
+        s.color = C4{m.color[0], m.color[1], m.color[2], m.color[3]};
+        s.emission = mk(m.emission[0], m.emission[1], m.emission[2]);
+        s.metallic = m.metallic;
+        s.roughness = m.roughness;
+        s.ior = m.ior;
+        return s;
+    }
     DevAttr at;
     {
         const float4 *p = reinterpret_cast<const float4 *>(S.attrs + h.k);
@@ -824,7 +875,7 @@ DEV ShadeResult shade_hit(const DevScene &S, const Hit &h, V3 ro, V3 rd, R &rng,
         out.term = ld3(S.bg) * mk(1, 1, 1); // Scene::bg_at with the 1x1 white bg (scene.h:83-89)
         return out;
     }
-    const Surf ii = make_surf<STATS>(S, h, rd, s_lin, s_gam, st);
+    const Surf ii = make_surf<STATS>(S, h, ro, rd, s_lin, s_gam, st);
     const V3 pos = ro + rd * h.t;                          // ray.at(t)
     if (!(uniform_real(rng, 0.0f, 1.0f) <= ii.color.a)) { // !coin(alpha) :559-561
         out.nro = pos;

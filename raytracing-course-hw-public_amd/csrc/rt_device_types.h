@@ -13,7 +13,10 @@
 #pragma once
 #include <stdint.h>
 
+#include "../../include/rt_abi.h"
+
 #define RT_NONE 0xFFFFFFFFu
+#define RT_PRIM_FLAG 0x40000000u /* hit record: k = RT_PRIM_FLAG | analytic primitive index (a DevTri index is < 2^27) */
 #define RT_LEAF_FLAG 0x80000000u
 /* leaf ref = RT_LEAF_FLAG | cnt << 27 | first DevTri index (27 bits). cnt = number of triangles if 1..8, 0 = "walk the
    leaf with the per-triangle first/last flags" (larger leaves). */
@@ -106,27 +109,29 @@ struct DevScene {
     float bg[3];
     uint32_t ray_depth;
     float bounds_lo[3], bounds_inv[3]; // scene AABB: lo and 1/extent, for the ray-ordering key of the wavefront pipeline
+    const rt_primitive_desc *prims; // analytic primitives of the scene-txt front end (include/rt_primspec.h), brute force
+    uint32_t n_prims;
+    uint32_t n_triangles;           // scene.objects.size(): rt_cast_rays reports analytic primitive i as n_triangles + i
 };
 
 struct DevStats { // device-side counters, see rt_stats in include/rt_abi.h
     unsigned long long samples, casts, nodes, box_tests, tri_tests, shaded, lq, lnodes, lbox, ltri, lhits, texels;
 };
 
-// ---- wavefront pipeline (rt_wavefront.hip): path = one (pixel, sample); queues hold live rays between bounces
-// Queue records, one per live ray, in two parallel arrays: the ray (32 B, all wf_extend gathers) and the path's RNG
-// state (16 B). The state of a path travels WITH its ray through the queues, so wf_shade reads and writes it with the
-// coalesced queue traffic instead of a random record per hit.
-struct alignas(16) WfRay {
+// ---- wavefront pipeline (rt_wavefront.hip): path = one (pixel, sample); queues hold live paths between bounces
+// Queue record, one per live path (64 B = one HBM request): the ray (first 32 B: all wf_extend and wf_sort_keys read) and
+// the path's RNG state (next 16 B). The state of a path travels WITH its ray through the queues, so wf_shade finds ray
+// and state with one gather and writes both with the coalesced queue traffic instead of a random per-path record.
+struct alignas(64) WfPath {
     float o[3];
     float dx;
     float dy, dz;
     uint32_t path;  // path id within the pass = index into fold / sample_out
     uint32_t depth; // low 16 bits: remaining trace_ray budget (raytracer.h:596); high 16 bits: pending shade() frames
+    uint32_t s[4];  // xoshiro128++ state
+    uint32_t pad[4];
 };
-static_assert(sizeof(WfRay) == 32, "WfRay must be 32 bytes");
-struct alignas(16) WfRng {
-    uint32_t s[4]; // xoshiro128++ state
-};
+static_assert(sizeof(WfPath) == 64, "WfPath must be 64 bytes");
 struct alignas(16) WfHit { // 16 B: closest hit of the ray in the same queue slot
     uint32_t k;            // DevTri index (scene-BVH order) or RT_NONE
     float b, c, t;
@@ -149,16 +154,18 @@ struct WfLaunch {
     uint32_t ray_depth;
     uint64_t seed;
     float tan_x, tan_y;
-    WfRay *rays_in, *rays_out;
-    WfRng *rng_in, *rng_out; // parallel to rays_in / rays_out
-    WfHit *hits;
+    WfPath *paths_in, *paths_out; // this bounce's queue / the next one (compacted survivors)
+    WfHit *hits;             // closest hit of the ray processed at queue POSITION q (position in `order` when sorted): wf_extend's
+                             // waves take contiguous positions, so a line of hits is filled by one wave within one chunk and
+                             // leaves L2 as a full line (stored at the ray's own slot, sorted rays scattered 16-B stores over
+                             // the whole array: 9x HBM write amplification, profiles/r02_write_amp.txt)
     WfFold *fold;            // [n_paths][ray_depth]: pending shade() frames, a path's frames contiguous (its unwind reads 1-2 lines)
     RtF4 *sample_out;        // [n_paths]: sanitised radiance of each finished sample
     RtF4 *accum;             // [pass_pixels]: running per-pixel sum across sample passes (reference order)
     float *fb;               // width*height*3
     uint32_t *counters;      // WF_CNT_*
     void *diag;              // development census (-DRT_DIAG), 32 x u64, else unused
-    const uint32_t *order;   // optional: extend processes queue slots in this order (coherence sort); null = identity
+    const uint32_t *order;   // optional: position q processes queue slot order[q] (coherence sort; extend AND shade); null = identity
     uint32_t *sort_keys[2];  // sort workspace: keys / slot indices, double buffered
     uint32_t *sort_vals[2];
     void *sort_temp;

@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const De
         if (state == ST_READY) {
             DIAG(9, 1);
             DIAG_LANES(10);
-            const Hit h = T.best;
+            Hit h = T.best;
+            if (S.n_prims)
+                prims_closest(S, T.o, T.d, h);
             if (h.k != RT_NONE)
                 depth_left -= 1; // shade(..., max_depth - 1)
             const ShadeResult sr = shade_hit<Rng<MODE>, STATS>(S, h, T.o, T.d, rng, has_lights, stk, s_lin, s_gam, st);
@@ -231,12 +233,14 @@ __global__ __launch_bounds__(256) void cast_kernel(const DevScene S, const float
     trav_init(T, S.scene, ld3(rays + 6ull * i), ld3(rays + 6ull * i + 3));
     while (T.cur != T_DONE)
         trav_step<false>(T, S.scene, stk, EPS, st);
-    const Hit h = T.best;
+    Hit h = T.best;
+    if (S.n_prims)
+        prims_closest(S, T.o, T.d, h);
     if (h.k == RT_NONE) {
         prim_out[i] = RT_NONE;
         bct_out[3ull * i] = bct_out[3ull * i + 1] = bct_out[3ull * i + 2] = 0.0f;
     } else {
-        prim_out[i] = S.scene.tris[h.k].prim;
+        prim_out[i] = (h.k & RT_PRIM_FLAG) ? S.n_triangles + (h.k & ~RT_PRIM_FLAG) : S.scene.tris[h.k].prim;
         bct_out[3ull * i] = h.b;
         bct_out[3ull * i + 1] = h.c;
         bct_out[3ull * i + 2] = h.t;

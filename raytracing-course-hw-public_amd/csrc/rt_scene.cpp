@@ -20,6 +20,7 @@
 #include "rt_device_types.h"
 #include "rt_error.h"
 #include "rt_film.h"
+#include "rt_group.h"
 #include "rt_kernels.h"
 
 namespace {
@@ -67,6 +68,7 @@ inline float len_h(V3h a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
 } // namespace
 
 struct rt_scene {
+    rt::Group *group = nullptr; // multi-GPU scene: replicas + RCCL communicator (rt_group.cpp); the fields below stay unused
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -126,8 +128,7 @@ struct rt_scene {
     uint64_t wf_paths_cap = 0, wf_pixels_cap = 0;
     uint32_t wf_depth_cap = 0;
     std::vector<void *> wf_owned;
-    WfRay *wf_rays[2] = {nullptr, nullptr};
-    WfRng *wf_rng[2] = {nullptr, nullptr};
+    WfPath *wf_paths[2] = {nullptr, nullptr};
     WfHit *wf_hits = nullptr;
     WfFold *wf_fold = nullptr;
     RtF4 *wf_samples = nullptr, *wf_accum = nullptr;
@@ -154,8 +155,7 @@ struct rt_scene {
             return RT_OK;
         };
         int rc;
-        if ((rc = alloc(paths * sizeof(WfRay), (void **)&wf_rays[0])) != RT_OK || (rc = alloc(paths * sizeof(WfRay), (void **)&wf_rays[1])) != RT_OK ||
-            (rc = alloc(paths * sizeof(WfRng), (void **)&wf_rng[0])) != RT_OK || (rc = alloc(paths * sizeof(WfRng), (void **)&wf_rng[1])) != RT_OK ||
+        if ((rc = alloc(paths * sizeof(WfPath), (void **)&wf_paths[0])) != RT_OK || (rc = alloc(paths * sizeof(WfPath), (void **)&wf_paths[1])) != RT_OK ||
             (rc = alloc(paths * sizeof(WfHit), (void **)&wf_hits)) != RT_OK || (rc = alloc(paths * depth * sizeof(WfFold), (void **)&wf_fold)) != RT_OK ||
             (rc = alloc(paths * sizeof(RtF4), (void **)&wf_samples)) != RT_OK || (rc = alloc(pixels * sizeof(RtF4), (void **)&wf_accum)) != RT_OK ||
             (rc = alloc(WF_CNT_WORDS * sizeof(uint32_t) + 1024, (void **)&wf_counters)) != RT_OK)
@@ -175,6 +175,10 @@ struct rt_scene {
     }
 
     ~rt_scene() {
+        if (group) {
+            rt::group_destroy(group);
+            return;
+        }
         (void)hipSetDevice(device);
         if (wf_host_count)
             (void)hipHostFree(wf_host_count);
@@ -378,6 +382,16 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
         if (pool.size() >= ((size_t)1 << 32))
             return rt::fail(RT_ERR_OOM, "rt_create: texture pool exceeds 2^32 texels");
     }
+    // ---- analytic primitives of the scene-txt front end (rt_primspec.h)
+    std::vector<rt_primitive_desc> prims;
+    if (d->n_primitives) {
+        if (!d->primitives || d->n_primitives > RT_MAX_PRIMITIVES)
+            return rt::fail(RT_ERR_INVALID_ARG, "rt_create: bad primitive list (limit " + std::to_string(RT_MAX_PRIMITIVES) + ")");
+        prims.assign(d->primitives, d->primitives + d->n_primitives);
+        for (const rt_primitive_desc &pr : prims)
+            if ((pr.kind != RT_PRIM_ELLIPSOID && pr.kind != RT_PRIM_PLANE) || pr.material_id >= d->n_materials)
+                return rt::fail(RT_ERR_INVALID_ARG, "rt_create: primitive with unknown kind or material id out of range");
+    }
     std::vector<float> lut_lin(256), lut_gam(256);
     for (int k = 0; k < 256; ++k) {
         lut_lin[k] = k / 255.0f;               // Texture::load_img geometry.h:593-594
@@ -410,6 +424,10 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
         return rc;
     if ((rc = upload(lut_gam, &D.lut_gamma, s->owned)) != RT_OK)
         return rc;
+    if ((rc = upload(prims, &D.prims, s->owned)) != RT_OK)
+        return rc;
+    D.n_prims = (uint32_t)prims.size();
+    D.n_triangles = n;
     std::memcpy(D.cam_pos, d->camera.position, 12);
     std::memcpy(D.cam_right, d->camera.right, 12);
     std::memcpy(D.cam_up, d->camera.up, 12);
@@ -440,7 +458,7 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
     return RT_OK;
 }
 
-extern "C" int rt_create(const rt_scene_desc *desc, int device, rt_scene **out) {
+static int check_desc(const rt_scene_desc *desc, const void *out) {
     if (!desc || !out)
         return rt::fail(RT_ERR_INVALID_ARG, "rt_create: null argument");
     if (desc->abi_version != RT_ABI_VERSION)
@@ -451,6 +469,36 @@ extern "C" int rt_create(const rt_scene_desc *desc, int device, rt_scene **out) 
         return rt::fail(RT_ERR_INVALID_ARG, "rt_create: null geometry array");
     if (desc->n_triangles > RT_LEAF_BEGIN_MASK)
         return rt::fail(RT_ERR_INVALID_ARG, "rt_create: too many triangles (limit 2^27 - 1)");
+    return RT_OK;
+}
+
+extern "C" int rt_create_on(const rt_scene_desc *desc, const int *devices, int n_devices, rt_scene **out) {
+    if (int rc = check_desc(desc, out); rc != RT_OK)
+        return rc;
+    if (!devices || n_devices < 1)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_create_on: empty device list");
+    rt::Group *g = nullptr;
+    if (int rc = rt::group_create(desc, devices, n_devices, &g); rc != RT_OK)
+        return rc;
+    rt_scene *s = new rt_scene();
+    s->group = g;
+    s->device = devices[0];
+    *out = s;
+    return RT_OK;
+}
+
+extern "C" int rt_create(const rt_scene_desc *desc, int device, rt_scene **out) {
+    if (int rc = check_desc(desc, out); rc != RT_OK)
+        return rc;
+    if (device == RT_ALL_DEVICES) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            return rt::fail(RT_ERR_NO_DEVICE, "rt_create: no HIP device available (this library has no CPU fallback)");
+        std::vector<int> all(ndev);
+        for (int i = 0; i < ndev; ++i)
+            all[i] = i;
+        return rt_create_on(desc, all.data(), ndev, out);
+    }
     rt_scene *s = new rt_scene();
     int rc = create_impl(desc, device, s);
     if (rc != RT_OK) {
@@ -461,12 +509,16 @@ extern "C" int rt_create(const rt_scene_desc *desc, int device, rt_scene **out) 
     return RT_OK;
 }
 
+extern "C" int rt_scene_device_count(const rt_scene *scene) { return !scene ? 0 : (scene->group ? rt::group_size(scene->group) : 1); }
+
 extern "C" void rt_destroy(rt_scene *scene) { delete scene; }
 
 // rt_render (fb_rgb: linear float3) and rt_render_rgb8 (rgb8_out: the tone-mapped image, film on the device)
 static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *rgb8_out, rt_stats *stats) {
     if (!s || !p || (!fb_rgb && !rgb8_out))
         return rt::fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
+    if (s->group)
+        return rt::group_render(s->group, p, fb_rgb, rgb8_out, stats);
     if (p->width == 0 || p->height == 0 || (uint64_t)p->width * p->height >= 0x7FFFFFFFull)
         return rt::fail(RT_ERR_INVALID_ARG, "Illegal image size" + std::to_string(p->width) + "x" + std::to_string(p->height)); // image.h:26
     if (p->rng_mode != RT_RNG_DEVICE && p->rng_mode != RT_RNG_REFERENCE)
@@ -549,13 +601,13 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
     if (L.n_items > 0 && wavefront) {
         // ---- production path: wavefront pipeline over (pixel tile) x (sample range) passes, all stream-ordered
         // Paths per pass: the larger a pass, the smaller the share of each bounce launch's drain phase (measured on
-        // S-sponza 1000x1000x64: 8 M paths 148, 16 M 158, 32 M 164, 64 M 167 Msamples/s). 64 M paths x 400 B = 26.8 GB
+        // S-sponza 1000x1000x64: 8 M paths 148, 16 M 158, 32 M 164, 64 M 167 Msamples/s). 64 M paths x 432 B = 29 GB
         // of workspace, sized for 288 GB of HBM; capped by free device memory below.
         uint64_t max_paths = 64ull << 20;
         {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                const uint64_t per_path = 2 * (sizeof(WfRay) + sizeof(WfRng)) + sizeof(WfHit) + s->dev.ray_depth * sizeof(WfFold) + sizeof(RtF4) + 16 /* sort keys + slots */;
+                const uint64_t per_path = 2 * sizeof(WfPath) + sizeof(WfHit) + s->dev.ray_depth * sizeof(WfFold) + sizeof(RtF4) + 16 /* sort keys + slots */;
                 const uint64_t have = free_b + s->wf_paths_cap * per_path; // what is already ours can be reused
                 const uint64_t fit = (uint64_t)(0.6 * (double)have) / per_path;
                 max_paths = std::max<uint64_t>(1u << 16, std::min(max_paths, fit));
@@ -579,10 +631,8 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
         W.seed = p->seed;
         W.tan_x = L.tan_x;
         W.tan_y = L.tan_y;
-        W.rays_in = s->wf_rays[0];
-        W.rays_out = s->wf_rays[1];
-        W.rng_in = s->wf_rng[0];
-        W.rng_out = s->wf_rng[1];
+        W.paths_in = s->wf_paths[0];
+        W.paths_out = s->wf_paths[1];
         W.hits = s->wf_hits;
         W.fold = s->wf_fold;
         W.sample_out = s->wf_samples;
@@ -688,6 +738,8 @@ extern "C" int rt_render_rgb8(rt_scene *s, const rt_params *p, uint8_t *rgb8, rt
 }
 
 extern "C" int rt_film_rgb8(rt_scene *s, const float *rgb, size_t n_pixels, uint8_t *out_rgb8) {
+    if (s && s->group)
+        return rt_film_rgb8(rt::group_primary(s->group), rgb, n_pixels, out_rgb8);
     if (!s || (n_pixels && (!rgb || !out_rgb8)) || n_pixels >= 0x7FFFFFFFull)
         return rt::fail(RT_ERR_INVALID_ARG, "rt_film_rgb8: bad argument");
     if (n_pixels == 0)
@@ -706,6 +758,8 @@ extern "C" int rt_film_rgb8(rt_scene *s, const float *rgb, size_t n_pixels, uint
 }
 
 extern "C" int rt_cast_rays(rt_scene *s, const float *rays, uint32_t n, uint32_t *prim_out, float *bct_out) {
+    if (s && s->group)
+        return rt_cast_rays(rt::group_primary(s->group), rays, n, prim_out, bct_out);
     if (!s || (n && (!rays || !prim_out || !bct_out)))
         return rt::fail(RT_ERR_INVALID_ARG, "rt_cast_rays: null argument");
     if (n == 0)
@@ -734,6 +788,8 @@ extern "C" int rt_cast_rays(rt_scene *s, const float *rays, uint32_t n, uint32_t
 }
 
 extern "C" int rt_light_pdf(rt_scene *s, const float *rays, uint32_t n, float *pdf_out) {
+    if (s && s->group)
+        return rt_light_pdf(rt::group_primary(s->group), rays, n, pdf_out);
     if (!s || (n && (!rays || !pdf_out)))
         return rt::fail(RT_ERR_INVALID_ARG, "rt_light_pdf: null argument");
     if (n == 0)
@@ -760,6 +816,8 @@ extern "C" int rt_bvh_info(rt_scene *s, int which, uint32_t *n_nodes, uint32_t *
                            uint32_t *order_out) {
     if (!s || which < 0 || which > 1)
         return rt::fail(RT_ERR_INVALID_ARG, "rt_bvh_info: bad argument");
+    if (s->group)
+        return rt_bvh_info(rt::group_primary(s->group), which, n_nodes, n_objects, root, nodes_out, order_out);
     const rt::HostBvh &b = s->host_bvh[which];
     if (n_nodes)
         *n_nodes = (uint32_t)b.nodes.size();

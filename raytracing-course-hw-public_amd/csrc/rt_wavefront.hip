@@ -20,7 +20,7 @@
 //
 // Every path owns an xoshiro128++ stream seeded from (seed, pixel, sample) and consumes it in the reference's draw
 // order; the stream's state, the remaining depth and the count of pending frames travel with the ray through the queues
-// (WfRay / WfRng), so the image is independent of queue order, tiling and GPU count, and bit-identical to the persistent
+// (WfPath), so the image is independent of queue order, tiling and GPU count, and bit-identical to the persistent
 // megakernel of rt_kernels.hip and to the CPU oracle in device-RNG mode.
 #include <cstring>
 #include <vector>
@@ -78,16 +78,10 @@ template <bool STATS> __global__ __launch_bounds__(256) void wf_generate(const D
         float sx = (2 * ((float)(int)x + ox) / (float)L.width - 1) * L.tan_x;
         float sy = (2 * ((float)(int)y + oy) / (float)L.height - 1) * L.tan_y;
         V3 rd = norm(sx * cam_right - sy * cam_up + 1.0f * cam_fwd);
-        WfRay r;
-        r.o[0] = cam_pos.x, r.o[1] = cam_pos.y, r.o[2] = cam_pos.z;
-        r.dx = rd.x, r.dy = rd.y, r.dz = rd.z;
-        r.path = i;
-        r.depth = L.ray_depth; // no pending frames yet
-        float4 *rq = reinterpret_cast<float4 *>(L.rays_in + i);
-        const float4 *rs = reinterpret_cast<const float4 *>(&r);
-        rq[0] = rs[0];
-        rq[1] = rs[1];
-        *reinterpret_cast<uint4 *>(L.rng_in + i) = make_uint4(rng.g.s[0], rng.g.s[1], rng.g.s[2], rng.g.s[3]);
+        float4 *rq = reinterpret_cast<float4 *>(L.paths_in + i);
+        rq[0] = make_float4(cam_pos.x, cam_pos.y, cam_pos.z, rd.x);
+        rq[1] = make_float4(rd.y, rd.z, __uint_as_float(i), __uint_as_float(L.ray_depth)); // path id; full budget, no pending frames
+        *reinterpret_cast<uint4 *>(rq + 2) = make_uint4(rng.g.s[0], rng.g.s[1], rng.g.s[2], rng.g.s[3]);
         st.cast(); // ray_depth >= 1: trace_ray casts (raytracer.h:600)
     }
     st.flush(L.stats);
@@ -204,6 +198,19 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
     uint32_t slot = RT_NONE;
     bool exhausted = n_in == 0; // wave-uniform
     uint32_t q_lo = 0, q_hi = 0; // this wave's private range of queue positions
+#ifdef RT_DIAG_CYCLES
+    // section census of the persistent loop (development build only, no other instrumentation): wave cycles between s_memtime stamps
+    unsigned long long dg_refill = 0, dg_node = 0, dg_leaf = 0, dg_pop = 0, dg_store = 0, dg_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long dg_start = dg_t;
+#define DG_STAMP(acc)                                             \
+    do {                                                          \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        acc += now_ - dg_t;                                       \
+        dg_t = now_;                                              \
+    } while (0)
+#else
+#define DG_STAMP(acc) do { } while (0)
+#endif
     for (;;) {
         const bool idle = T.cur == T_DONE;
         const unsigned long long im = __ballot(idle);
@@ -226,16 +233,17 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
             if (idle && rank < avail) {
                 const uint32_t jq = q_lo + rank;
                 const uint32_t j = L.order ? L.order[jq] : jq; // coherence-sorted processing order
-                const float4 *rq = reinterpret_cast<const float4 *>(L.rays_in + j);
+                const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
                 const float4 r0 = rq[0], r1 = rq[1];
-                slot = j;
+                slot = jq; // the hit goes to the queue POSITION (see WfLaunch::hits)
                 trav_init(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y));
                 if (T.cur == T_DONE) // no geometry at all: immediate miss
-                    *reinterpret_cast<float4 *>(L.hits + j) = make_float4(__uint_as_float(RT_NONE), 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4 *>(L.hits + jq) = make_float4(__uint_as_float(RT_NONE), 0.f, 0.f, 0.f);
             }
             q_lo += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
         }
         DIAG(12, 1);
+        DG_STAMP(dg_refill);
         const bool active = T.cur != T_DONE;
         const bool at_leaf = active && (T.cur & RT_LEAF_FLAG) != 0 && RT_LEAF_CNT(T.cur) != 0;
         const bool stepper = active && !at_leaf; // inner node, or a big leaf walked triangle by triangle
@@ -247,6 +255,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
         }
         if (sm == 0ull || __popcll(lm) >= RT_EXT_LEAF_MIN) {
             leaf_batch<STATS>(T, S.scene, at_leaf, s_owner, s_min, s_bc, st);
+            DG_STAMP(dg_leaf);
         } else {
             // the common wave: every stepping lane is on an inner node with the fast-division guarantees -> straight-line
             // node step; a wave with a big-leaf walker or a guarded ray takes the general step
@@ -260,12 +269,48 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
             } else if (stepper) {
                 trav_step_core<STATS>(T, S.scene, stk, EPS, st);
             }
+            DG_STAMP(dg_node);
         }
         trav_pop_wave(T, stk); // unwind after a leaf batch or a node step, all lanes of the wave together
+        DG_STAMP(dg_pop);
         if (active && T.cur == T_DONE)
             *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
+        DG_STAMP(dg_store);
     }
+#ifdef RT_DIAG_CYCLES
+    if ((threadIdx.x & 63u) == 0u && L.diag) {
+        unsigned long long *dg = reinterpret_cast<unsigned long long *>(L.diag);
+        atomicAdd(dg + 20, dg_refill);
+        atomicAdd(dg + 21, dg_node);
+        atomicAdd(dg + 22, dg_leaf);
+        atomicAdd(dg + 23, dg_pop);
+        atomicAdd(dg + 24, dg_store);
+        atomicAdd(dg + 25, __builtin_amdgcn_s_memtime() - dg_start);
+        atomicAdd(dg + 26, 1ull);
+    }
+#endif
     st.flush(L.stats);
+}
+
+// ------------------------------------------------------------------------------------------------ extend: analytic primitives
+// Scenes of the scene-txt front end may hold analytic primitives (ELLIPSOID / PLANE, include/rt_primspec.h) next to their
+// triangles. They have no BVH (a plane is unbounded; BASELINE config 2 is "intersect kernel only, no BVH"): every queued
+// ray tests all of them in index order and keeps the nearer of (BVH hit, primitive hit), strict-less as bvh.h:132.
+// One lane per ray, records coalesced; launched only when the scene has such primitives.
+__global__ __launch_bounds__(256) void wf_extend_prims(const DevScene S, const WfLaunch L) {
+    const uint32_t n_in = L.counters[WF_CNT_IN];
+    for (uint32_t jq = blockIdx.x * blockDim.x + threadIdx.x; jq < n_in; jq += gridDim.x * blockDim.x) {
+        const uint32_t j = L.order ? L.order[jq] : jq;
+        const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
+        const float4 r0 = rq[0], r1 = rq[1];
+        const float4 hq = *reinterpret_cast<const float4 *>(L.hits + jq);
+        Hit h;
+        h.k = __float_as_uint(hq.x), h.b = hq.y, h.c = hq.z, h.t = hq.w;
+        const uint32_t k0 = h.k;
+        prims_closest(S, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), h);
+        if (h.k != k0)
+            *reinterpret_cast<float4 *>(L.hits + jq) = make_float4(__uint_as_float(h.k), h.b, h.c, h.t);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ shade
@@ -283,16 +328,17 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
     const uint32_t stride = gridDim.x * blockDim.x;
     // wave-uniform trip count: ballots below must see the whole wave
     for (uint32_t base = blockIdx.x * blockDim.x; base < n_in; base += stride) {
-        const uint32_t j = base + threadIdx.x;
-        const bool active = j < n_in;
+        const uint32_t jq = base + threadIdx.x; // queue position: where wf_extend left this ray's hit
+        const bool active = jq < n_in;
         bool survive = false;
-        WfRay nr;
+        float4 nr0 = make_float4(0.f, 0.f, 0.f, 0.f), nr1 = nr0;
         uint4 nrng = make_uint4(0u, 0u, 0u, 0u);
         if (active) {
-            const float4 *rq = reinterpret_cast<const float4 *>(L.rays_in + j);
+            const uint32_t j = L.order ? L.order[jq] : jq;
+            const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
             const float4 r0 = rq[0], r1 = rq[1];
-            const uint4 p0 = *reinterpret_cast<const uint4 *>(L.rng_in + j);
-            const float4 hq = *reinterpret_cast<const float4 *>(L.hits + j);
+            const uint4 p0 = *reinterpret_cast<const uint4 *>(rq + 2);
+            const float4 hq = *reinterpret_cast<const float4 *>(L.hits + jq);
             const uint32_t path = __float_as_uint(r1.z);
             Rng<RT_RNG_DEVICE> rng;
             rng.g.s[0] = p0.x, rng.g.s[1] = p0.y, rng.g.s[2] = p0.z, rng.g.s[3] = p0.w;
@@ -334,10 +380,8 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
             } else {
                 survive = true;
                 st.cast();
-                nr.o[0] = sr.nro.x, nr.o[1] = sr.nro.y, nr.o[2] = sr.nro.z;
-                nr.dx = sr.nrd.x, nr.dy = sr.nrd.y, nr.dz = sr.nrd.z;
-                nr.path = path;
-                nr.depth = depth_left | (nb << 16);
+                nr0 = make_float4(sr.nro.x, sr.nro.y, sr.nro.z, sr.nrd.x);
+                nr1 = make_float4(sr.nrd.y, sr.nrd.z, __uint_as_float(path), __uint_as_float(depth_left | (nb << 16)));
                 nrng = make_uint4(rng.g.s[0], rng.g.s[1], rng.g.s[2], rng.g.s[3]);
             }
         }
@@ -351,11 +395,10 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
                 obase = atomicAdd(L.counters + WF_CNT_OUT, (uint32_t)__popcll(m));
             obase = __shfl(obase, leader);
             if (survive) {
-                float4 *rw = reinterpret_cast<float4 *>(L.rays_out + obase + rank);
-                const float4 *rs = reinterpret_cast<const float4 *>(&nr);
-                rw[0] = rs[0];
-                rw[1] = rs[1];
-                *reinterpret_cast<uint4 *>(L.rng_out + obase + rank) = nrng;
+                float4 *rw = reinterpret_cast<float4 *>(L.paths_out + obase + rank);
+                rw[0] = nr0;
+                rw[1] = nr1;
+                *reinterpret_cast<uint4 *>(rw + 2) = nrng;
             }
         }
     }
@@ -375,7 +418,7 @@ DEV uint32_t spread3(uint32_t v) { // 6 bits -> every third bit
 }
 __global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLaunch L, uint32_t n) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const float4 *rq = reinterpret_cast<const float4 *>(L.rays_in + j);
+        const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
         const float4 r0 = rq[0], r1 = rq[1];
         const float fx = (r0.x - S.bounds_lo[0]) * S.bounds_inv[0], fy = (r0.y - S.bounds_lo[1]) * S.bounds_inv[1], fz = (r0.z - S.bounds_lo[2]) * S.bounds_inv[2];
         const uint32_t cx = (uint32_t)fminf(fmaxf(fx * 64.0f, 0.0f), 63.0f), cy = (uint32_t)fminf(fmaxf(fy * 64.0f, 0.0f), 63.0f), cz = (uint32_t)fminf(fmaxf(fz * 64.0f, 0.0f), 63.0f);
@@ -436,7 +479,7 @@ __global__ __launch_bounds__(256) void wf_resolve(const WfLaunch L, int first_pa
 namespace rt {
 
 // One pass of the pipeline, fully stream-ordered (no host synchronisation): generate, ray_depth x (extend, shade,
-// advance), resolve. `L.rays_in/rays_out` are swapped locally per bounce.
+// advance), resolve. `L.paths_in/paths_out` are swapped locally per bounce.
 // every launch is checked: a failed launch (bad configuration, lost device) must not turn into a silently wrong image
 #define WF_LAUNCH(...)                                  \
     do {                                                \
@@ -492,17 +535,16 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
             WF_LAUNCH((wf_extend<false>), dim3(ext_blocks), block, 0, stream, S, L);
         if (e0 && e1)
             (void)hipEventRecord(e1, stream);
+        if (S.n_prims)
+            WF_LAUNCH(wf_extend_prims, dim3(shade_blocks), block, 0, stream, S, L);
         if (stats)
             WF_LAUNCH((wf_shade<true>), dim3(shade_blocks), block, 0, stream, S, L);
         else
             WF_LAUNCH((wf_shade<false>), dim3(shade_blocks), block, 0, stream, S, L);
         WF_LAUNCH(wf_advance, dim3(1), dim3(64), 0, stream, L.counters);
-        WfRay *t = L.rays_in;
-        L.rays_in = L.rays_out;
-        L.rays_out = t;
-        WfRng *tr = L.rng_in;
-        L.rng_in = L.rng_out;
-        L.rng_out = tr;
+        WfPath *t = L.paths_in;
+        L.paths_in = L.paths_out;
+        L.paths_out = t;
     }
     const int res_blocks = (int)((L.pass_pixels + 255u) / 256u);
     WF_LAUNCH(wf_resolve, dim3(res_blocks > 0 ? res_blocks : 1), block, 0, stream, L, first_pass ? 1 : 0, last_pass ? 1 : 0);

@@ -65,6 +65,8 @@ class Scene:
     camera: Optional[Camera] = None
     bg_color: tuple = (1.0, 1.0, 1.0)
     ray_depth: int = 8
+    # analytic primitives of the scene-txt front end: dicts {kind, material_id, param[3], position[3], rotation xyzw[4]}
+    primitives: List[dict] = field(default_factory=list)
 
     @property
     def n_triangles(self) -> int:
@@ -422,3 +424,20 @@ def write_gltf(scene: Scene, path: str) -> str:
     with open(base + ".gltf", "w") as f:
         json.dump(doc, f)
     return base + ".gltf"
+
+
+def scene_from_arrays(a: dict, yfov: float = 0.9, rotation=(0.0, 0.0, 0.0, 1.0), face_normals: bool = False) -> Scene:
+    """A Scene from the arrays of a host loader (LoadedScene.arrays()), e.g. to export a scene-txt file's triangles as glTF
+    for the reference binary (`yfov` / `rotation` are what write_gltf puts on the camera node: they must describe the same
+    camera as a['camera'], which glTF cannot express directly). face_normals=True drops the per-vertex normals so that every
+    consumer derives the face normal itself (a glTF primitive without NORMAL, scene.h:427-430)."""
+    mats = []
+    for m in a["materials"]:
+        mats.append(Material(color=tuple(float(x) for x in m["color"]), emission=tuple(float(x) for x in m["emission"]), emissive_strength=None,
+                             roughness=float(m["roughness"]), metallic=float(m["metallic"]), ior=float(m["ior"]), color_tex=int(m["color_tex"]),
+                             emissive_tex=int(m["emissive_tex"]), metallic_roughness_tex=int(m["metallic_roughness_tex"]), normal_tex=int(m["normal_tex"])))
+    c = a["camera"]
+    cam = Camera(position=c["position"], right=c["right"], up=c["up"], forward=c["forward"], fov_x=float(c["fov_x"]), yfov=yfov, rotation=rotation)
+    return Scene(positions=a["positions"], normals=None if face_normals else a["normals"], texcoords=a["texcoords"], tangents=a["tangents"], material_ids=a["material_ids"], materials=mats,
+                 textures=list(a["textures"]), camera=cam, bg_color=tuple(float(x) for x in a["bg_color"]), ray_depth=int(a["ray_depth"]),
+                 primitives=[dict(p) for p in a.get("primitives", [])])

@@ -61,6 +61,10 @@ def golden_scene_specs():
         "open_nolight": dict(kind="room", n_random=400, seed=13, n_lights=0, n_materials=6, tex_size=0, open_room=True),
         # S-small: boxes + emissive triangles (axis-aligned, flat AABBs: the hard case for bit-exact traversal)
         "boxes": dict(kind="boxes", n_boxes=24, seed=14, n_lights=3),
+        # 40 emissive triangles: a light BVH with inner nodes (19 nodes), so BVH::foreach_intersection's inner-node path
+        # (bvh.h:237-260) and uniform_int(0, n - 1) with n = 40 (raytracer.h:353-375) are pinned at more than the
+        # bench scene's light count; textured, alpha pass-through materials
+        "room_manylights": dict(kind="room", n_random=450, seed=15, n_lights=40, n_materials=6, tex_size=16, n_tex_sets=2, alpha_fraction=0.2, light_strength=6.0),
     }
 
 

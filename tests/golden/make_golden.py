@@ -39,10 +39,14 @@ def main():
     assert oracle.have_reference_build(), "build oracle/_ref first (make -C oracle)"
     import make_features_gltf
 
-    jobs = [(name, spec) for name, spec in golden_scene_specs().items()] + [("features", None)]
+    jobs = [(name, spec) for name, spec in golden_scene_specs().items()] + [("features", None), ("txt_boxes", "txt")]
     for name, spec in jobs:
         with tempfile.TemporaryDirectory() as td:
-            if spec is None:  # the hand-built loader-feature scene: the glTF itself is a committed fixture
+            if spec == "txt":  # scene-txt fixture with BOX / TRIANGLE primitives only: its triangles, exported as glTF
+                a = rt.parse_scene_txt(os.path.join(HERE, "txt", "boxes_only.txt")).arrays()
+                sc = rt.scenegen.scene_from_arrays(a, yfov=0.8, rotation=(0.0, 0.0, 0.0, 1.0), face_normals=True)
+                gltf = rt.scenegen.write_gltf(sc, os.path.join(td, name + ".gltf"))
+            elif spec is None:  # the hand-built loader-feature scene: the glTF itself is a committed fixture
                 gltf = make_features_gltf.build(os.path.join(HERE, "features"))
                 import types
 

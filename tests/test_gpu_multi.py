@@ -1,0 +1,87 @@
+"""Multi-GPU scenes inside the library (rt_create with RT_ALL_DEVICES / rt_create_on; csrc/rt_group.cpp): replicas, interleaved
+blocks, gather on the first GPU. A one-GPU box can run (a) the real RCCL path with G = 1, where RT_GROUP_SELF_EXCHANGE routes
+the GPU's own blocks through pack -> ncclSend/ncclRecv -> unpack, and (b) G > 1 with repeated ordinals over the peer-copy
+rehearsal transport (RCCL refuses a device twice in one communicator — which is also how RT_ERR_COMM is provoked)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene(sg):
+    return sg.room_scene(900, seed=51, n_lights=5, n_materials=6, tex_size=16, n_tex_sets=2, alpha_fraction=0.2)
+
+
+@pytest.fixture(scope="module")
+def single(gpu, scene):
+    dev = gpu.DeviceScene(scene)
+    yield dev
+    dev.close()
+
+
+W, H, SPP = 72, 50, 4  # 3600 pixels: not a multiple of any block size used below -> a partial last block
+
+
+def test_all_devices_scene_uses_rccl_and_matches_single_gpu(gpu, scene, single, monkeypatch):
+    """rt_create(RT_ALL_DEVICES): communicator created inside rt_create (ncclCommInitAll over every visible GPU); with
+    RT_GROUP_SELF_EXCHANGE the first GPU's own blocks travel through ncclSend/ncclRecv as well, so the RCCL exchange really
+    runs even with one GPU. Images must equal the single-GPU render bit for bit (float and rgb8)."""
+    monkeypatch.setenv("RT_GROUP_SELF_EXCHANGE", "1")
+    grp = gpu.DeviceScene(scene, device=gpu.RT_ALL_DEVICES)
+    try:
+        assert grp.n_devices == gpu.device_count() >= 1 and single.n_devices == 1
+        want, wst = single.run_raytracer(W, H, SPP, seed=7, counters=True)
+        for block in (0, 256, 1000):
+            got, gst = grp.run_raytracer(W, H, SPP, seed=7, shard_block=block, counters=True)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), block
+            for k in ("samples", "casts", "nodes_visited", "tri_tests", "shaded_hits", "texel_fetches"):
+                assert gst[k] == wst[k], k
+        img, _ = grp.run_raytracer_rgb8(W, H, SPP, seed=7)
+        assert np.array_equal(img, gpu.tonemap(want))
+        ref, _ = single.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE)
+        got, _ = grp.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        # the probe entry points are served by the first GPU's replica
+        rays = np.random.default_rng(3).normal(size=(500, 6)).astype(np.float32)
+        assert np.array_equal(grp.cast_rays(rays)[0], single.cast_rays(rays)[0])
+        assert np.array_equal(grp.bvh_info(0)["nodes"], single.bvh_info(0)["nodes"])
+        with pytest.raises(gpu.RtError) as e:  # a group shards by itself
+            grp.run_raytracer(W, H, 1, shard_index=0, shard_count=2, shard_block=256)
+        assert e.value.code == 1
+    finally:
+        grp.close()
+
+
+@pytest.mark.parametrize("G", [2, 3, 5])
+def test_replicated_render_over_rehearsal_transport(gpu, scene, single, monkeypatch, G):
+    """G replicas (all on GPU 0) with one host thread each, interleaved blocks, packed slabs gathered on rank 0 and
+    de-interleaved: everything of the multi-GPU flow except the RCCL calls themselves (peer copies stand in for them)."""
+    monkeypatch.setenv("RT_GROUP_TRANSPORT", "copy")
+    grp = gpu.DeviceScene(scene, device=[0] * G)
+    try:
+        assert grp.n_devices == G
+        want, _ = single.run_raytracer(W, H, SPP, seed=9)
+        for block in (0, 256, 700):
+            got, st = grp.run_raytracer(W, H, SPP, seed=9, shard_block=block)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (G, block)
+            assert st["samples"] == W * H * SPP
+        img, _ = grp.run_raytracer_rgb8(W, H, SPP, seed=9)
+        assert np.array_equal(img, gpu.tonemap(want))
+        ref, _ = single.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE)
+        got, _ = grp.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    finally:
+        grp.close()
+
+
+def test_rccl_refusal_is_reported_as_comm_error(gpu, scene, monkeypatch):
+    """The same GPU twice in one communicator: ncclCommInitAll refuses -> RT_ERR_COMM with RCCL's message, no crash,
+    no half-built scene left behind."""
+    monkeypatch.delenv("RT_GROUP_TRANSPORT", raising=False)
+    with pytest.raises(gpu.RtError) as e:
+        gpu.DeviceScene(scene, device=[0, 0])
+    assert e.value.code == 7, str(e.value)  # RT_ERR_COMM
+    with pytest.raises(gpu.RtError) as e:
+        gpu.DeviceScene(scene, device=[0, 99])
+    assert e.value.code in (1, 3)  # invalid ordinal: reported by the replica's rt_create

@@ -30,7 +30,7 @@ def pairs(gpu, oracle, scenes):
         o.close()
 
 
-@pytest.mark.parametrize("name", ["room_plain", "room_textured", "open_nolight", "boxes"])
+@pytest.mark.parametrize("name", ["room_plain", "room_textured", "open_nolight", "boxes", "room_manylights"])
 def test_bvh_topology_matches_oracle(pairs, name):
     dev, orc, _ = pairs[name]
     for which in (0, 1):
@@ -40,7 +40,7 @@ def test_bvh_topology_matches_oracle(pairs, name):
         assert np.array_equal(a["nodes"], b["nodes"])
 
 
-@pytest.mark.parametrize("name", ["room_plain", "room_textured", "open_nolight", "boxes"])
+@pytest.mark.parametrize("name", ["room_plain", "room_textured", "open_nolight", "boxes", "room_manylights"])
 def test_closest_hit_bit_exact(pairs, name):
     dev, orc, sc = pairs[name]
     rays = random_rays(sc, 20000, seed=101)
@@ -88,7 +88,7 @@ def test_closest_hit_fast_division_boundaries(pairs):
     assert (gp != 0xFFFFFFFF).sum() > 2000
 
 
-@pytest.mark.parametrize("name", ["room_plain", "room_textured", "boxes"])
+@pytest.mark.parametrize("name", ["room_plain", "room_textured", "boxes", "room_manylights"])
 def test_light_pdf_bit_exact(pairs, name):
     dev, orc, sc = pairs[name]
     rays = random_rays(sc, 20000, seed=77)
@@ -105,7 +105,7 @@ def test_light_pdf_bit_exact(pairs, name):
     assert (o > 0).sum() > 100
 
 
-@pytest.mark.parametrize("name", ["room_plain", "room_textured", "open_nolight", "boxes"])
+@pytest.mark.parametrize("name", ["room_plain", "room_textured", "open_nolight", "boxes", "room_manylights"])
 def test_render_device_rng_matches_oracle(pairs, gpu, name):
     """RT_RNG_DEVICE: same xoshiro streams + shared sincos on both sides -> radiance within 1e-5 relative
     (observed: bit-identical), identical event counters."""
@@ -122,7 +122,7 @@ def test_render_device_rng_matches_oracle(pairs, gpu, name):
     assert np.array_equal(gpu.tonemap(gfb), gpu.tonemap(ofb))
 
 
-@pytest.mark.parametrize("name", ["room_plain", "room_textured"])
+@pytest.mark.parametrize("name", ["room_plain", "room_textured", "room_manylights"])
 def test_render_reference_rng_matches_oracle(pairs, gpu, name):
     """RT_RNG_REFERENCE: the reference's minstd stream per 256-pixel span, one lane per span. With the shared sincos
     on both sides the framebuffers must agree to 1e-5 (observed: bit-identical) -> identical PPM bytes."""
@@ -164,7 +164,8 @@ def test_full_size_bench_scene_parity(gpu, oracle, sg):
     render, ray ordering on/off and pass size do not change a bit."""
     import os
 
-    sc = sg.room_scene(262144, seed=0x5EED5EED, tex_size=256, n_tex_sets=16, n_materials=64, n_lights=16, light_strength=20.0,
+    # tex_size 1024 = exactly bench.py's scene: the 268 MB interleaved texel pool and its tiling are the tested ones
+    sc = sg.room_scene(262144, seed=0x5EED5EED, tex_size=1024, n_tex_sets=16, n_materials=64, n_lights=16, light_strength=20.0,
                        alpha_fraction=0.02, offset=0.15, camera=sg.look_camera((-15.0, 4.0, 0.0), yaw_deg=-90.0, yfov=0.9))
     dev = gpu.DeviceScene(sc)
     orc = oracle.OracleScene(sc)

@@ -1,0 +1,81 @@
+"""BASELINE config 5 (S-10M: 10^7 random triangles, 2048x2048) as a TESTED configuration: the HIP path through the C-ABI
+against the CPU oracle at full scene size, plus the size-independent properties on the full image.
+
+The oracle cannot render 4 M pixels of this scene in seconds, so the pixel comparison takes every 64th 256-pixel span of
+the 2048x2048 image (65 536 pixels spread over the whole frame, shard_count = 64) at 1 SPP; hit records are compared on
+20 000 random rays; the rest are properties that need no oracle (wavefront == megakernel, union of 8 shards == single
+render, pass splitting). RT_TEST_S10M_TRIANGLES overrides the triangle count for a quicker local run.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import random_rays
+
+pytestmark = pytest.mark.gpu
+
+COUNTERS = ("samples", "casts", "nodes_visited", "box_tests", "tri_tests", "shaded_hits", "light_queries", "light_nodes", "light_box_tests",
+            "light_tri_tests", "light_hits", "texel_fetches")
+
+
+def test_s10m_full_size_parity_and_properties(gpu, oracle, sg):
+    n = int(float(os.environ.get("RT_TEST_S10M_TRIANGLES", "1e7")))
+    W = H = 2048
+    sc = sg.room_scene(n, seed=0x5EED5EED, tex_size=256, n_tex_sets=16, n_materials=64, n_lights=16, light_strength=20.0, alpha_fraction=0.02,
+                       offset=0.03, camera=sg.look_camera((-15.0, 4.0, 0.0), yaw_deg=-90.0, yfov=0.9))
+    dev = gpu.DeviceScene(sc)
+    orc = oracle.OracleScene(sc)
+    try:
+        # the BVH rt_create flattened and uploaded is the oracle's (reference topology), node for node
+        for which in (0, 1):
+            a, b = dev.bvh_info(which), orc.bvh_info(which)
+            assert a["root"] == b["root"] and np.array_equal(a["order"], b["order"]) and np.array_equal(a["nodes"], b["nodes"])
+        if n >= 10_000_000:
+            assert a["nodes"].shape[0] > 1 and dev.bvh_info(0)["nodes"].shape[0] > 4_000_000
+        # every 64th span of the full-size image at 1 SPP: bit-exact radiance + identical event counters
+        gfb = np.full((H, W, 3), -1.0, dtype=np.float32)
+        ofb = np.full((H, W, 3), -1.0, dtype=np.float32)
+        _, gst = dev.run_raytracer(W, H, 1, seed=0x5EED5EED, shard_index=5, shard_count=64, shard_block=256, out=gfb, counters=True)
+        _, ost = orc.run_raytracer(W, H, 1, seed=0x5EED5EED, shard_index=5, shard_count=64, shard_block=256, out=ofb)
+        assert np.array_equal(gfb.view(np.uint32), ofb.view(np.uint32)), f"{int((gfb != ofb).any(axis=2).sum())} of {W * H // 64} pixels differ"
+        assert int((gfb[..., 0] != -1.0).sum()) == W * H // 64
+        for k in COUNTERS:
+            assert gst[k] == ost[k], (k, gst[k], ost[k])
+        assert gst["casts"] > 150_000 and gst["nodes_visited"] / gst["casts"] > 100  # deep traversals really happened
+        # 20 000 random rays: bit-exact hit records (primitive index, b, c, t)
+        rays = random_rays(sc, 20000, seed=77)
+        gp, gb = dev.cast_rays(rays)
+        op, ob = orc.cast_rays(rays)
+        assert np.array_equal(gp, op), f"{int((gp != op).sum())} hit-index mismatches"
+        assert np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+        assert (gp != 0xFFFFFFFF).sum() > 15000
+        g = dev.light_pdf(rays)
+        o = orc.light_pdf(rays)
+        assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+    finally:
+        orc.close()
+    # ---- size-independent properties on the whole 2048x2048 image (4 M pixels x 2 SPP = 8 M paths)
+    a, ast = dev.run_raytracer(W, H, 2, seed=11, counters=True)
+    assert np.isfinite(a).all() and a.mean() > 1e-4
+    m, mst = dev.run_raytracer(W, H, 2, seed=11, megakernel=True, counters=True)
+    assert np.array_equal(a.view(np.uint32), m.view(np.uint32)), "wavefront pipeline != persistent megakernel"
+    for k in COUNTERS:
+        assert ast[k] == mst[k], k
+    sh = np.zeros_like(a)
+    for r in range(8):
+        dev.run_raytracer(W, H, 2, seed=11, shard_index=r, shard_count=8, shard_block=8 * W, out=sh)
+    assert np.array_equal(sh.view(np.uint32), a.view(np.uint32)), "union of 8 shards != single render"
+    old = os.environ.get("RT_WF_MAX_PATHS")
+    try:
+        os.environ["RT_WF_MAX_PATHS"] = str(3_000_000)  # several pixel tiles x sample passes
+        b, _ = dev.run_raytracer(W, H, 2, seed=11)
+    finally:
+        if old is None:
+            os.environ.pop("RT_WF_MAX_PATHS", None)
+        else:
+            os.environ["RT_WF_MAX_PATHS"] = old
+    assert np.array_equal(b.view(np.uint32), a.view(np.uint32))
+    img, _ = dev.run_raytracer_rgb8(W, H, 2, seed=11)
+    assert np.array_equal(img, gpu.tonemap(a))
+    dev.close()

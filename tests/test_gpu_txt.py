@@ -1,0 +1,137 @@
+"""Scene-txt scenes on the GPU (BASELINE configs 1-2): triangles from BOX / TRIANGLE primitives through the BVH
+path, ELLIPSOID / PLANE through the brute-force analytic-primitive kernel (wf_extend_prims; include/rt_primspec.h), against
+the CPU oracle on the same loaded scene. Analytic primitives are "parity unpinned" against the reference (HEAD has none);
+the bar here is oracle == GPU bit for bit, in both schedules (wavefront pipeline and megakernel)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TXT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "txt")
+COUNTERS = ("samples", "casts", "nodes_visited", "box_tests", "tri_tests", "shaded_hits", "light_queries", "light_tri_tests", "light_hits")
+
+SPHERES_ONLY = """DIMENSIONS 512 512
+RAY_DEPTH 6
+SAMPLES 64
+BG_COLOR 0.6 0.7 0.9
+CAMERA_POSITION 0 1 12
+CAMERA_RIGHT 1 0 0
+CAMERA_UP 0 1 0
+CAMERA_FORWARD 0 0 -1
+CAMERA_FOV_X 0.927295218
+NEW_PRIMITIVE
+PLANE 0 1 0
+POSITION 0 -2 0
+COLOR 0.8 0.8 0.8
+NEW_PRIMITIVE
+ELLIPSOID 2 2 2
+POSITION -2.5 0 0
+COLOR 0.9 0.3 0.3
+NEW_PRIMITIVE
+ELLIPSOID 1.5 2.5 1
+POSITION 2 0.5 -1
+ROTATION 0.1 0.2 0.3 0.9273618
+COLOR 0.3 0.9 0.4
+METALLIC
+NEW_PRIMITIVE
+ELLIPSOID 1 1 1
+POSITION 0.3 -1 3
+COLOR 0.9 0.9 0.9
+DIELECTRIC
+IOR 1.5
+NEW_PRIMITIVE
+ELLIPSOID 0.7 0.7 0.7
+POSITION 0 4.5 1
+EMISSION 6 5 4
+"""
+
+
+def _pair(gpu, oracle, path):
+    ls = gpu.parse_scene_txt(path)
+    return gpu.DeviceScene(ls), oracle.OracleScene(ls), ls
+
+
+def _rays(seed, n, lo=-6.0, hi=6.0):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(lo, hi, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, d], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["cornell_mixed", "boxes_only"])
+def test_txt_scene_matches_oracle(gpu, oracle, name):
+    dev, orc, ls = _pair(gpu, oracle, os.path.join(TXT, name + ".txt"))
+    try:
+        W, H, SPP = 64, 56, 6
+        ofb, ost = orc.run_raytracer(W, H, SPP, seed=31)
+        for kw in ({}, {"megakernel": True}):
+            gfb, gst = dev.run_raytracer(W, H, SPP, seed=31, counters=True, **kw)
+            assert np.array_equal(gfb.view(np.uint32), ofb.view(np.uint32)), (name, kw, int((gfb != ofb).any(axis=2).sum()))
+            for k in COUNTERS:
+                assert gst[k] == ost[k], (k, kw)
+        rays = _rays(4, 20000)
+        gp, gb = dev.cast_rays(rays)
+        op, ob = orc.cast_rays(rays)
+        assert np.array_equal(gp, op) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+        n_tri = ls.arrays()["positions"].shape[0]
+        if name == "cornell_mixed":
+            assert (gp >= n_tri).sum() > 5000 and (gp < n_tri).sum() > 500  # analytic primitives AND triangles win rays
+        assert np.array_equal(dev.light_pdf(rays).view(np.uint32), orc.light_pdf(rays).view(np.uint32))
+        img, _ = dev.run_raytracer_rgb8(W, H, SPP, seed=31)
+        assert np.array_equal(img, oracle.tonemap(ofb))
+        sh = np.zeros_like(ofb)
+        for r in range(3):
+            dev.run_raytracer(W, H, SPP, seed=31, shard_index=r, shard_count=3, shard_block=256, out=sh)
+        assert np.array_equal(sh.view(np.uint32), ofb.view(np.uint32))
+        rfb, _ = dev.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE)
+        orf, _ = orc.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE, libm_sincos=False)
+        assert np.array_equal(rfb.view(np.uint32), orf.view(np.uint32))
+    finally:
+        dev.close()
+        orc.close()
+
+
+def test_config2_primitives_only_512x512(gpu, oracle, tmp_path):
+    """BASELINE config 2 shape: spheres / planes only (no triangle, no BVH: the intersect kernel alone), 512x512. Bit-exact
+    against the oracle at 4 SPP; at the configuration's 64 SPP the two GPU schedules must agree with each other."""
+    f = tmp_path / "spheres.txt"
+    f.write_text(SPHERES_ONLY)
+    dev, orc, ls = _pair(gpu, oracle, str(f))
+    try:
+        a = ls.arrays()
+        assert a["positions"].shape[0] == 0 and len(a["primitives"]) == 5
+        W = H = 512
+        ofb, ost = orc.run_raytracer(W, H, 4, seed=5)
+        gfb, gst = dev.run_raytracer(W, H, 4, seed=5, counters=True)
+        assert np.array_equal(gfb.view(np.uint32), ofb.view(np.uint32))
+        assert gst["casts"] == ost["casts"] and gst["shaded_hits"] == ost["shaded_hits"] and gst["nodes_visited"] == 0
+        full, fst = dev.run_raytracer(W, H, 64, seed=5)
+        mega, _ = dev.run_raytracer(W, H, 64, seed=5, megakernel=True)
+        assert np.array_equal(full.view(np.uint32), mega.view(np.uint32)) and np.isfinite(full).all()
+        assert fst["samples"] == W * H * 64
+        gp, gb = dev.cast_rays(_rays(9, 5000, -8, 8))
+        op, ob = orc.cast_rays(_rays(9, 5000, -8, 8))
+        assert np.array_equal(gp, op) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+    finally:
+        dev.close()
+        orc.close()
+
+
+def test_cli_renders_a_scene_txt(gpu, oracle, tmp_path):
+    """run.sh <scene.txt> <W> <H> <SPP> <out.ppm>: the reference's CLI shape with the scene-txt front end behind it."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(TXT, "cornell_mixed.txt")
+    out = tmp_path / "c.ppm"
+    env = dict(os.environ, RT_SEED="9", RT_RNG_MODE="device", RT_DEVICE="0")
+    subprocess.check_call([os.path.join(root, "run.sh"), src, "48", "40", "3", str(out)], env=env)
+    ls = gpu.parse_scene_txt(src)
+    fb, _ = oracle.OracleScene(ls).run_raytracer(48, 40, 3, rng_mode=gpu.RT_RNG_DEVICE, seed=9)
+    assert np.array_equal(oracle.read_ppm(str(out)), oracle.tonemap(fb))
+    bad = tmp_path / "bad.txt"
+    bad.write_text("NEW_PRIMITIVE\nTORUS 1 2\n")
+    r = subprocess.run([os.path.join(root, "run.sh"), str(bad), "8", "8", "1", str(out)], capture_output=True, text=True, env=env)
+    assert r.returncode == 1 and "unknown command 'TORUS'" in r.stderr

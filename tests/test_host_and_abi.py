@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(rt):
     assert "rt_render" in names and "rt_create" in names and "rt_gltf_load" in names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ but not exported by librt_amd.so"
-    assert lib.rt_abi_version() == 1
+    assert lib.rt_abi_version() == 2
 
 
 def test_ctypes_prototypes_cover_the_headers(rt):
@@ -43,15 +43,16 @@ def test_struct_layouts_match_the_c_headers(rt, tmp_path):
     abi = __import__("importlib").import_module("raytracing-course-hw-public_amd._ctypes_abi")
     src = tmp_path / "sz.c"
     src.write_text(
-        '#include <stdio.h>\n#include <stddef.h>\n#include "rt_abi.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+        '#include <stdio.h>\n#include <stddef.h>\n#include "rt_abi.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
         "sizeof(rt_camera),sizeof(rt_texture_desc),sizeof(rt_material_desc),sizeof(rt_scene_desc),sizeof(rt_params),sizeof(rt_stats),"
-        "offsetof(rt_scene_desc,camera),offsetof(rt_params,seed));return 0;}\n"
+        "offsetof(rt_scene_desc,camera),offsetof(rt_params,seed),sizeof(rt_primitive_desc),offsetof(rt_scene_desc,primitives),offsetof(rt_primitive_desc,rotation));return 0;}\n"
     )
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(abi.RtCamera), ctypes.sizeof(abi.RtTextureDesc), ctypes.sizeof(abi.RtMaterialDesc), ctypes.sizeof(abi.RtSceneDesc),
-            ctypes.sizeof(abi.RtParams), ctypes.sizeof(abi.RtStats), abi.RtSceneDesc.camera.offset, abi.RtParams.seed.offset]
+            ctypes.sizeof(abi.RtParams), ctypes.sizeof(abi.RtStats), abi.RtSceneDesc.camera.offset, abi.RtParams.seed.offset,
+            ctypes.sizeof(abi.RtPrimitiveDesc), abi.RtSceneDesc.primitives.offset, abi.RtPrimitiveDesc.rotation.offset]
     assert got == want
 
 

@@ -141,16 +141,49 @@ def test_product_host_bvh_builder_matches_reference(rt, loaded, name):
     assert np.array_equal(bl["nodes"], g["light_nodes"]) and np.array_equal(bl["order"], g["light_order"])
 
 
-def test_parallel_subtree_build_is_bit_identical(rt, sg, oracle):
-    """Above 65 536 triangles the builder splits the top of the tree into parallel tasks; node numbering, boxes and the
-    object permutation must still equal the (sequential, literal) oracle build."""
+def test_parallel_subtree_build_is_bit_identical(rt, sg, oracle, monkeypatch):
+    """Above 65 536 triangles the product's builder AND the oracle split the top of the tree into parallel tasks; node
+    numbering, boxes and the object permutation must equal the sequential, literal oracle build (plain build_node)."""
     sc = sg.room_scene(150000, seed=3, n_lights=8, tex_size=0)
     b = rt.bvh_build_host(sc.positions)
+    monkeypatch.setenv("RTO_BUILD_PARALLEL_LEVELS", "0")
     ob = oracle.OracleScene(sc).bvh_info(0)
-    assert b["root"] == ob["root"]
+    monkeypatch.setenv("RTO_BUILD_PARALLEL_LEVELS", "4")
+    op = oracle.OracleScene(sc).bvh_info(0)
+    assert b["root"] == ob["root"] == op["root"]
     assert np.array_equal(b["nodes"], ob["nodes"]) and np.array_equal(b["order"], ob["order"])
+    assert np.array_equal(op["nodes"], ob["nodes"]) and np.array_equal(op["order"], ob["order"])
     leaves = b["nodes"][b["nodes"][:, 6] == 0xFFFFFFFF]
     assert (leaves[:, 9] - leaves[:, 8]).sum() == sc.n_triangles
+
+
+def test_live_reference_bvh_dump_at_100k_if_present(oracle, rt, sg, tmp_path):
+    """The reference's own BVH::build (through oracle/_ref/ref_probe) on 100 000 triangles against the oracle's parallel
+    build and the product's host builder: nodes and object order bit for bit. Container only (needs oracle/_ref)."""
+    if not oracle.have_reference_build():
+        pytest.skip("oracle/_ref not built (GPU box): covered by the committed fixtures")
+    sc = sg.room_scene(100000, seed=99, n_lights=20, n_materials=4, tex_size=0, offset=0.05)
+    path = sg.write_gltf(sc, str(tmp_path / "big.gltf"))
+    oracle.ref_probe("bvh", path, 64, 48, str(tmp_path / "bvh.bin"))
+    words = np.fromfile(str(tmp_path / "bvh.bin"), dtype=np.uint32)
+    ls = rt.parse_gltf_scene(path, 64 / 48)
+    orc = oracle.OracleScene(ls)
+    a = ls.arrays()
+    lights = np.array([i for i, m in enumerate(a["material_ids"]) if np.any(a["materials"][int(m)]["emission"] != 0)], dtype=np.uint32)
+    p = 0
+    for which, sub in ((0, None), (1, lights)):
+        nn, no, root = (int(x) for x in words[p : p + 3])
+        p += 3
+        nodes = words[p : p + 10 * nn].reshape(nn, 10)
+        p += 10 * nn
+        order = words[p : p + no]
+        p += no
+        ob = orc.bvh_info(which)
+        pb = rt.bvh_build_host(a["positions"], sub)
+        assert ob["root"] == root == pb["root"]
+        assert np.array_equal(ob["nodes"], nodes) and np.array_equal(ob["order"], order), which
+        assert np.array_equal(pb["nodes"], nodes) and np.array_equal(pb["order"], order), which
+    assert nn > 1  # 20 lights: a light BVH with inner nodes
 
 
 def test_oracle_thread_count_does_not_change_the_image(oracles, rt):
