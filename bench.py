@@ -27,10 +27,14 @@ The "roofline" object (dominant kernel wf_extend):
                        kernel variant; cache hits are NOT subtracted) / the live HIP-event launch duration, against the
                        nominal 8 TB/s. This is the contract's figure; it can exceed 1 when the working set is cache
                        resident (S-sponza), so it must not be read as HBM utilisation.
-  traffic / hbm_frac   HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) kept
-                       under profiles/ and stamped with the hash of the device sources they were measured on: used only
+  traffic / hbm_frac   HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE) kept
+                       under profiles/ (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and stamped with the
+                       hash of the device sources they were measured on: used only
                        while that hash matches the sources of this run, else null. hbm_frac = traffic / live launch
-                       duration / 8 TB/s is the fraction of the memory roofline actually used.
+                       duration / 8 TB/s is the fraction of the memory roofline actually used. request_frac = L2 read
+                       requests per launch / live launch duration / the ~55 G requests/s this chip sustains for random
+                       gathers of <= 64-B records (tools/ubench/gather64.hip, profiles/r02_gather64_calibration.txt): the
+                       practical roof of this kernel's access pattern, which is request-rate bound, not byte bound.
   limiter + pmc        what the SQ/TCP/TCC counters of the same committed profile say binds the kernel (VALU issue share,
                        active lanes per VALU instruction, wave-wait share, L2 hit rate), each with its source file.
 "cpu_baseline": the CPU oracle (port of the reference algorithm, byte-identical to the reference binary on the
@@ -248,13 +252,14 @@ def main() -> None:
 
     src_hash = kernel_source_hash()
     traffic, traffic_source = None, "not collected: PMC counters cannot run inside the timed bench"
-    pmc, limiter = None, None
+    pmc, limiter, requests, request_roof = None, None, None, None
     if world == 1:
         tj, traffic_source = load_profile("hbm_traffic", workload_id, src_hash)
         if tj is not None:
             traffic = tj.get("hbm_bytes_per_launch")
+            requests, request_roof = tj.get("read_requests_per_launch"), tj.get("request_roof_Greq_s")
             traffic_source = (f"{tj['_file']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command on the same device "
-                              "sources (hash checked); FETCH x2 per MI355X_MICROARCH.md; not measured in this run")
+                              "sources (hash checked); FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md; not measured in this run")
         pj, pmc_source = load_profile("pmc_wf_extend", workload_id, src_hash)
         if pj is not None:
             pmc = {k: pj.get(k) for k in ("valu_busy", "lanes_per_valu", "wait_any_frac", "l1_hit", "l2_hit", "salu_per_valu", "workload", "spp")}
@@ -274,6 +279,9 @@ def main() -> None:
         "traffic_source": traffic_source,
         "hbm_rate": round(traffic / avg_launch_s / 1e9, 2) if traffic else None,
         "hbm_frac": round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+        "request_rate_Greq_s": round(requests / avg_launch_s / 1e9, 2) if requests else None,
+        "request_roof_Greq_s": request_roof,
+        "request_frac": round(requests / avg_launch_s / 1e9 / request_roof, 4) if requests and request_roof else None,
         "limiter": limiter,
         "pmc": pmc,
         "peak_measured_read": stream_peak,

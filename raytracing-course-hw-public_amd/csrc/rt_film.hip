@@ -57,6 +57,7 @@ hipError_t launch_film(const float *fb_rgb, uint8_t *out_rgb8, uint32_t n_pixels
     if (n_pixels == 0)
         return hipSuccess;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n_pixels + 255) / 256, 256u * 16u);
+    (void)hipGetLastError(); // clear the thread's sticky error state: what is returned below belongs to this launch
     hipLaunchKernelGGL(film_kernel, dim3(blocks), dim3(256), 0, stream, fb_rgb, out_rgb8, n_pixels, shard_index, shard_count ? shard_count : 1u,
                        shard_block ? shard_block : n_pixels, d_table);
     return hipGetLastError();

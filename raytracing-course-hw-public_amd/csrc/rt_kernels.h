@@ -6,6 +6,15 @@
 
 #include "rt_device_types.h"
 
+// Launch + check. hipGetLastError() reports the last error of ANY earlier HIP call of this thread (e.g. a refused
+// hipSetDevice in another scene's rt_create), so the sticky state is cleared first: what comes back belongs to this launch.
+#define RT_LAUNCH_CHECKED(...)               \
+    ({                                       \
+        (void)hipGetLastError();             \
+        hipLaunchKernelGGL(__VA_ARGS__);     \
+        hipGetLastError();                   \
+    })
+
 namespace rt {
 // HIP events for per-launch timing, created once per scene and reused by every render (no create/destroy inside the
 // timed region). next() returns nullptr when an event cannot be created; pairs are taken in (start, stop) order.

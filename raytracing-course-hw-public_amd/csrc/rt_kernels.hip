@@ -267,30 +267,24 @@ hipError_t launch_render(const DevScene &S, const RenderLaunch &L, bool stats, i
     dim3 grid(blocks), block(256);
     if (L.rng_mode == RT_RNG_REFERENCE) {
         if (stats)
-            hipLaunchKernelGGL((render_kernel<RT_RNG_REFERENCE, true>), grid, block, 0, stream, S, L);
-        else
-            hipLaunchKernelGGL((render_kernel<RT_RNG_REFERENCE, false>), grid, block, 0, stream, S, L);
-    } else {
-        if (stats)
-            hipLaunchKernelGGL((render_kernel<RT_RNG_DEVICE, true>), grid, block, 0, stream, S, L);
-        else
-            hipLaunchKernelGGL((render_kernel<RT_RNG_DEVICE, false>), grid, block, 0, stream, S, L);
+            return RT_LAUNCH_CHECKED((render_kernel<RT_RNG_REFERENCE, true>), grid, block, 0, stream, S, L);
+        return RT_LAUNCH_CHECKED((render_kernel<RT_RNG_REFERENCE, false>), grid, block, 0, stream, S, L);
     }
-    return hipGetLastError();
+    if (stats)
+        return RT_LAUNCH_CHECKED((render_kernel<RT_RNG_DEVICE, true>), grid, block, 0, stream, S, L);
+    return RT_LAUNCH_CHECKED((render_kernel<RT_RNG_DEVICE, false>), grid, block, 0, stream, S, L);
 }
 
 hipError_t launch_cast(const DevScene &S, const float *rays, uint32_t n, uint32_t *prim, float *bct, hipStream_t stream) {
     if (n == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(cast_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, rays, n, prim, bct);
-    return hipGetLastError();
+    return RT_LAUNCH_CHECKED(cast_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, rays, n, prim, bct);
 }
 
 hipError_t launch_light_pdf(const DevScene &S, const float *rays, uint32_t n, float *pdf, hipStream_t stream) {
     if (n == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(light_pdf_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, rays, n, pdf);
-    return hipGetLastError();
+    return RT_LAUNCH_CHECKED(light_pdf_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, rays, n, pdf);
 }
 
 } // namespace rt

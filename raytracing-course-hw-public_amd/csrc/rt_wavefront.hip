@@ -483,8 +483,7 @@ namespace rt {
 // every launch is checked: a failed launch (bad configuration, lost device) must not turn into a silently wrong image
 #define WF_LAUNCH(...)                                  \
     do {                                                \
-        hipLaunchKernelGGL(__VA_ARGS__);                \
-        if (hipError_t le_ = hipGetLastError(); le_ != hipSuccess) \
+        if (hipError_t le_ = RT_LAUNCH_CHECKED(__VA_ARGS__); le_ != hipSuccess) \
             return le_;                                 \
     } while (0)
 

@@ -45,9 +45,18 @@ if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
     write = agg["WRITE_SIZE"] / n["WRITE_SIZE"]
     out = {
         "workload": f"{workload} spp={W['spp_per_gpu']}", "kernel": "wf_extend<false>", "kernel_src_sha16": sha, "launches": n["FETCH_SIZE"],
-        "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
+        # MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 64 B per L2 read request although a request moves a 128-B line ->
+        # doubled, as the guide prescribes. The guide also says "other access widths are uncalibrated: calibrate on a known
+        # byte count in your own access pattern": tools/ubench/gather64.hip (profiles/r02_gather64_calibration.txt) shows
+        # ONE request per random 64-B record as well as per 128-B record, and a ceiling of ~55 G requests/s for either, so
+        # for wf_extend's <= 64-B gathers the REQUEST rate against that measured ceiling is the meaningful utilisation;
+        # both are reported.
+        "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "hbm_bytes_per_launch_fetch_x1": (fetch + write) * 1024,
+        "read_requests_per_launch": fetch * 1024 / 64.0, "request_roof_Greq_s": 55.0,
+        "request_roof_source": "profiles/r02_gather64_calibration.txt: random 64-B or 128-B records from 0.5-2 GiB tables complete at 52-57 G requests/s",
+        "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
         "avg_launch_ms_under_pmc": dur["FETCH_SIZE"] / n["FETCH_SIZE"],
-        "correction": "gfx950: FETCH_SIZE reports half of the fetched bytes -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; x1024 (KB)",
+        "correction": "gfx950: FETCH_SIZE reports 64 B per 128-B read request -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; x1024 (KB)",
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over python3 bench.py {'--workload ' + wl if wl != 'sponza' else ''} --no-cpu-baseline --steps 1 --warmup 0, averaged over the wf_extend<false> dispatches",
     }
     json.dump(out, open(os.path.join(O, f"{tag}_hbm_traffic_{wl}.json"), "w"), indent=1)

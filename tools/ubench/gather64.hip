@@ -5,11 +5,12 @@
 //   (2) the rate at which the chip sustains such gathers (records/s and useful GB/s), i.e. the practical memory roof for it.
 // Every lane reads REC bytes (64 or 128, as 16-B loads) at a pseudo-random record index; `loads in flight per lane` = 1
 // (dependent chain like a BVH descent: the next index depends on the loaded data) or 4 (independent).
-//   hipcc --offload-arch=gfx950 -O3 gather64.hip -o gather64 && ./gather64 [table GiB]
+//   hipcc --offload-arch=gfx950 -O3 gather64.hip -o gather64 && ./gather64 [table MiB ...]
 //   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out -- ./gather64     (counter per kernel launch; records per launch printed)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 __device__ __forceinline__ uint32_t mix(uint32_t x) {
     x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
@@ -33,43 +34,54 @@ template <int REC, bool DEPENDENT> __global__ __launch_bounds__(256) void k_gath
         out[0] = acc;
 }
 int main(int argc, char **argv) {
-    const size_t gib = argc > 1 ? (size_t)atoi(argv[1]) : 8;
-    const size_t bytes = gib << 30;
-    uint4 *tab;
+    // table sizes in MiB (powers of two); default: the footprints that matter for wf_extend (S-10M DevNode[] = 640 MB) up to
+    // far beyond every cache and TLB reach
+    std::vector<size_t> sizes;
+    for (int i = 1; i < argc; ++i)
+        sizes.push_back((size_t)atoll(argv[i]));
+    if (sizes.empty())
+        sizes = {512, 1024, 2048, 8192};
     uint32_t *o;
-    if (hipMalloc(&tab, bytes) != hipSuccess || hipMalloc(&o, 4) != hipSuccess)
+    if (hipMalloc(&o, 4) != hipSuccess)
         return 1;
-    hipMemset(tab, 0, bytes);
-    hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     const int blocks = 256 * 8; // 8 blocks of 256 threads per CU: 32 waves per CU
     const uint32_t iters = 256;
-    for (int variant = 0; variant < 4; ++variant) {
-        const int rec = (variant & 1) ? 128 : 64;
-        const bool dep = variant < 2;
-        const uint32_t mask = (uint32_t)(bytes / rec - 1);
-        float best = 1e9f;
-        for (int rep = 0; rep < 4; ++rep) {
-            hipEventRecord(e0);
-            if (rec == 64 && dep)
-                hipLaunchKernelGGL((k_gather<64, true>), dim3(blocks), dim3(256), 0, 0, tab, mask, iters, o);
-            else if (rec == 128 && dep)
-                hipLaunchKernelGGL((k_gather<128, true>), dim3(blocks), dim3(256), 0, 0, tab, mask, iters, o);
-            else if (rec == 64)
-                hipLaunchKernelGGL((k_gather<64, false>), dim3(blocks), dim3(256), 0, 0, tab, mask, iters, o);
-            else
-                hipLaunchKernelGGL((k_gather<128, false>), dim3(blocks), dim3(256), 0, 0, tab, mask, iters, o);
-            hipEventRecord(e1);
-            hipEventSynchronize(e1);
-            float ms;
-            hipEventElapsedTime(&ms, e0, e1);
-            if (rep > 0 && ms < best)
-                best = ms;
+    for (size_t mib : sizes) {
+        const size_t bytes = mib << 20;
+        uint4 *tab;
+        if (hipMalloc(&tab, bytes) != hipSuccess)
+            return 1;
+        hipMemset(tab, 0, bytes);
+        hipDeviceSynchronize();
+        for (int variant = 0; variant < 4; ++variant) {
+            const int rec = (variant & 1) ? 128 : 64;
+            const bool dep = variant < 2;
+            const uint32_t mask = (uint32_t)(bytes / rec - 1);
+            float best = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                hipEventRecord(e0);
+                if (rec == 64 && dep)
+                    hipLaunchKernelGGL((k_gather<64, true>), dim3(blocks), dim3(256), 0, 0, tab, mask, iters, o);
+                else if (rec == 128 && dep)
+                    hipLaunchKernelGGL((k_gather<128, true>), dim3(blocks), dim3(256), 0, 0, tab, mask, iters, o);
+                else if (rec == 64)
+                    hipLaunchKernelGGL((k_gather<64, false>), dim3(blocks), dim3(256), 0, 0, tab, mask, iters, o);
+                else
+                    hipLaunchKernelGGL((k_gather<128, false>), dim3(blocks), dim3(256), 0, 0, tab, mask, iters, o);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < best)
+                    best = ms;
+            }
+            const double recs = (double)blocks * 256 * iters;
+            printf("table %5zu MiB, record %3d B, %s chain: %.0f records per launch, %.3f ms, %.2f Grec/s, %.0f GB/s useful\n", mib, rec, dep ? "dependent  " : "independent", recs, best,
+                   recs / best / 1e6, recs * rec / best / 1e6);
         }
-        const double recs = (double)blocks * 256 * iters;
-        printf("table %zu GiB, record %3d B, %s chain: %.0f records per launch, %.3f ms, %.2f Grec/s, %.0f GB/s useful\n", gib, rec, dep ? "dependent  " : "independent", recs, best,
-               recs / best / 1e6, recs * rec / best / 1e6);
+        hipFree(tab);
     }
     return 0;
 }
