@@ -126,7 +126,16 @@ typedef struct rt_scene_desc {
     uint32_t ray_depth; /* Scene::ray_depth; 8 for glTF (scene.h:186, config.h:17) */
     uint32_t n_primitives; /* analytic primitives, tested by brute force next to the BVH (at most RT_MAX_PRIMITIVES) */
     const rt_primitive_desc *primitives;
+    uint32_t build_flags; /* RT_BUILD_* */
 } rt_scene_desc;
+/* How rt_create builds the scene BVH (BVH::build, bvh.h:262-393):
+ *   RT_BUILD_REFERENCE (default): on the host, in the reference's exact topology (same SAH sweep, same std::sort
+ *       permutation) -> event counters and tie-breaking equal the reference's: the parity mode.
+ *   RT_BUILD_DEVICE_LBVH: on the GPU (Morton sort + Karras radix tree + refit, csrc/rt_bvh_device.hip), tens of milliseconds
+ *       for 10^7 triangles instead of seconds. Same closest hits (identical t), but a different topology: ties between
+ *       equal-t triangles may resolve differently and the counters differ. Production mode for big scenes; also selected by
+ *       the environment variable RT_BVH_DEVICE=1. The light BVH (emissive triangles only) is always built on the host. */
+enum { RT_BUILD_REFERENCE = 0, RT_BUILD_DEVICE_LBVH = 1 };
 #define RT_MAX_PRIMITIVES 4096u
 
 typedef struct rt_params {
@@ -226,6 +235,14 @@ int rt_light_pdf(rt_scene *scene, const float *rays, uint32_t n, float *pdf_out)
  * (BVH::objects, bvh.h:166) as original triangle indices. Pass NULL buffers to query counts. */
 int rt_bvh_info(rt_scene *scene, int which, uint32_t *n_nodes, uint32_t *n_objects, uint32_t *root,
                 uint32_t *nodes_out /* 10*n_nodes */, uint32_t *order_out /* n_objects */);
+
+/* The BVH exactly as the traversal kernels see it, copied back from HBM (tests: validates what rt_create uploaded or built
+ * on the device, not a host copy). nodes64: n_inner records of 16 words {lmin.xyz, lmax.xyz, rmin.xyz, rmax.xyz, left,
+ * right, pad, pad}; a child ref is an inner index, or 0x80000000 | count << 27 | first triangle for a leaf. tris48: n_tris
+ * records of 12 words {a.xyz, (b-a).xyz, (c-a).xyz, original triangle index, flags, pad}. Pass NULL buffers for the counts. */
+int rt_bvh_device_dump(rt_scene *scene, int which, uint32_t *n_inner, uint32_t *n_tris, uint32_t *root, uint32_t *nodes64, uint32_t *tris48);
+/* Wall time of the last rt_create's scene-BVH build in ms: {host build + flatten, 0} or {device build, upload of the raw arrays}. */
+int rt_build_times(const rt_scene *scene, double *build_ms, double *upload_ms);
 
 /* Film (image.h:49-82): ACES -> gamma 1/2.2 -> x255 -> clamp -> round -> u8. Host function; n pixels. */
 void rt_tonemap_rgb8(const float *rgb, size_t n_pixels, uint8_t *out_rgb8);

@@ -23,6 +23,7 @@ from ._ctypes_abi import (
     HOST_PROTOTYPES,
     RT_FLAG_COUNTERS,
     RT_FLAG_DEVICE_FB,
+    RT_BUILD_DEVICE_LBVH,
     RT_FLAG_MEGAKERNEL,
     RT_OK,
     RT_RNG_DEVICE,
@@ -132,12 +133,18 @@ def _as_desc(scene) -> Tuple[RtSceneDesc, object]:
 class DeviceScene:
     """Device-resident scene + both BVHs: the RaytracerStaticContext of raytracer.h:434-455, in HBM."""
 
-    def __init__(self, scene, device=0):
-        """`device`: a HIP ordinal; RT_ALL_DEVICES (-1) for one replica per visible GPU + an RCCL communicator; or a list
+    def __init__(self, scene, device=0, device_bvh: bool = False):
+        """`device_bvh`: build the scene BVH on the GPU (RT_BUILD_DEVICE_LBVH: production mode, different topology) instead
+        of the reference-topology host build. `device`: a HIP ordinal; RT_ALL_DEVICES (-1) for one replica per visible GPU + an RCCL communicator; or a list
         of ordinals (rt_create_on). Multi-GPU scenes shard every render over their GPUs and gather on the first one."""
         desc, keep = _as_desc(scene)
         self._keep = keep
         self._h = C.c_void_p()
+        if device_bvh:  # a private copy of the descriptor with the build flag set
+            d2 = RtSceneDesc()
+            C.memmove(C.byref(d2), C.byref(desc), C.sizeof(RtSceneDesc))
+            d2.build_flags = RT_BUILD_DEVICE_LBVH
+            desc = d2
         if isinstance(device, (list, tuple)):
             devs = (C.c_int * len(device))(*[int(d) for d in device])
             _check(lib().rt_create_on(C.byref(desc), devs, len(device), C.byref(self._h)))
@@ -235,6 +242,20 @@ class DeviceScene:
         out = np.zeros(n, dtype=np.float32)
         _check(lib().rt_light_pdf(self._h, fptr(rays), n, fptr(out)))
         return out
+
+    def bvh_device_dump(self, which: int = 0):
+        """The BVH as the kernels see it, read back from HBM: {root, nodes (n_inner,16) u32, tris (n_tris,12) u32}."""
+        ni, nt, root = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib().rt_bvh_device_dump(self._h, which, C.byref(ni), C.byref(nt), C.byref(root), None, None))
+        nodes = np.zeros((ni.value, 16), dtype=np.uint32)
+        tris = np.zeros((nt.value, 12), dtype=np.uint32)
+        _check(lib().rt_bvh_device_dump(self._h, which, C.byref(ni), C.byref(nt), C.byref(root), u32ptr(nodes), u32ptr(tris)))
+        return {"root": root.value, "nodes": nodes, "tris": tris}
+
+    def build_times(self):
+        b, u = C.c_double(), C.c_double()
+        _check(lib().rt_build_times(self._h, C.byref(b), C.byref(u)))
+        return {"build_ms": b.value, "upload_ms": u.value}
 
     def bvh_info(self, which: int):
         nn, no, root = C.c_uint32(), C.c_uint32(), C.c_uint32()

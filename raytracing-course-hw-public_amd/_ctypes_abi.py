@@ -12,6 +12,8 @@ import numpy as np
 RT_ABI_VERSION = 2
 RT_PRIM_ELLIPSOID = 1
 RT_PRIM_PLANE = 2
+RT_BUILD_REFERENCE = 0
+RT_BUILD_DEVICE_LBVH = 1
 RT_TEX_NONE = -1
 RT_RNG_DEVICE = 0
 RT_RNG_REFERENCE = 1
@@ -93,6 +95,7 @@ class RtSceneDesc(C.Structure):
         ("ray_depth", C.c_uint32),
         ("n_primitives", C.c_uint32),
         ("primitives", C.POINTER(RtPrimitiveDesc)),
+        ("build_flags", C.c_uint32),
     ]
 
 
@@ -151,6 +154,8 @@ ABI_PROTOTYPES = {
     "rt_device_count": (C.c_int, []),
     "rt_create_on": (C.c_int, [C.POINTER(RtSceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "rt_scene_device_count": (C.c_int, [C.c_void_p]),
+    "rt_bvh_device_dump": (C.c_int, [C.c_void_p, C.c_int, c_u32_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
+    "rt_build_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 HOST_PROTOTYPES = {
     "rt_gltf_load": (C.c_int, [C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),
@@ -255,6 +260,7 @@ class DescHolder:
                 q.rotation[k] = np.float32(pr["rotation"][k])
         d.n_primitives = len(prims)
         d.primitives = self.primitives
+        d.build_flags = int(getattr(scene, "build_flags", 0))
         self.desc = d
 
 

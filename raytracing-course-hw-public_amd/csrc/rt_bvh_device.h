@@ -1,0 +1,23 @@
+// rt_bvh_device.h — device-side BVH construction (rt_bvh_device.hip); internal.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "../../include/rt_abi.h"
+#include "rt_device_types.h"
+
+namespace rt {
+
+struct DeviceBvh {
+    DevNode *nodes = nullptr; // device memory, owned by the caller after a successful build
+    DevTri *tris = nullptr;
+    DevAttr *attrs = nullptr;
+    uint32_t n_inner = 0, n_tris = 0, root = RT_NONE;
+    bool fast_ok = true;      // every vertex coordinate is 0 or within [2^-37, 2^40] in magnitude (div_exact_fast)
+    float lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
+    double upload_ms = 0, build_ms = 0;
+};
+
+// Linear BVH over all triangles of `d`, built on the current device on `stream` (blocking). On failure *err names the call.
+hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBvh *out, const char **err);
+
+} // namespace rt

@@ -17,6 +17,7 @@
 
 #include "../../include/rt_abi.h"
 #include "bvh_build.h"
+#include "rt_bvh_device.h"
 #include "rt_device_types.h"
 #include "rt_error.h"
 #include "rt_film.h"
@@ -77,6 +78,9 @@ struct rt_scene {
     rt_camera cam{};
     std::vector<void *> owned;
     rt::HostBvh host_bvh[2];
+    bool device_built = false; // scene BVH built by rt_bvh_device.hip: host_bvh[0] is reconstructed from HBM on demand
+    uint32_t dev_n_inner[2] = {0, 0};
+    double build_ms = 0, build_upload_ms = 0;
     uint32_t *d_counter = nullptr;
     DevStats *d_stats = nullptr;
     float *d_fb = nullptr;
@@ -243,27 +247,48 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
         if (!((e[0] == 0) & (e[1] == 0) & (e[2] == 0)))
             lights.push_back(i);
     }
-    s->host_bvh[0] = rt::build_bvh(d->positions, n, all);
-    s->host_bvh[1] = rt::build_bvh(d->positions, n, lights);
-    rt::FlatBvh flat[2] = {rt::flatten_bvh(s->host_bvh[0], d->positions), rt::flatten_bvh(s->host_bvh[1], d->positions)};
-
-    // ---- shading records in scene-BVH order
-    std::vector<DevAttr> attrs(flat[0].tris.size());
-    for (size_t k = 0; k < attrs.size(); ++k) {
-        const uint32_t t = flat[0].tris[k].prim;
-        DevAttr &a = attrs[k];
-        std::memset(&a, 0, sizeof(a));
-        std::memcpy(a.n, d->normals + 9 * (size_t)t, 36);
-        std::memcpy(a.tg, d->tangents + 9 * (size_t)t, 36);
-        std::memcpy(a.uv, d->texcoords + 6 * (size_t)t, 24);
-        const DevTri &tr = flat[0].tris[k];
-        V3h c = cross_h({tr.v[0], tr.v[1], tr.v[2]}, {tr.u[0], tr.u[1], tr.u[2]}); // triangle::normal geometry.h:477-479
-        float l = len_h(c);
-        a.gn[0] = c.x / l;
-        a.gn[1] = c.y / l;
-        a.gn[2] = c.z / l;
-        a.material = d->material_ids[t];
+    const char *env_dev = std::getenv("RT_BVH_DEVICE");
+    const bool dev_build = n > 0 && ((d->build_flags & RT_BUILD_DEVICE_LBVH) || (env_dev && std::atoi(env_dev) != 0));
+    rt::FlatBvh flat[2];
+    rt::DeviceBvh dbvh{};
+    std::vector<DevAttr> attrs;
+    const auto tb0 = std::chrono::steady_clock::now();
+    if (dev_build) {
+        // ---- production mode: the scene BVH, the triangle records and the shading records are built on the device
+        const char *what = "";
+        hipError_t be = rt::build_bvh_device(d, s->stream, &dbvh, &what);
+        if (be != hipSuccess)
+            return rt::fail(be == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string("device BVH build: ") + what + ": " + hipGetErrorString(be));
+        s->owned.push_back(dbvh.nodes);
+        s->owned.push_back(dbvh.tris);
+        s->owned.push_back(dbvh.attrs);
+        s->device_built = true;
+        s->build_ms = dbvh.build_ms;
+        s->build_upload_ms = dbvh.upload_ms;
+    } else {
+        s->host_bvh[0] = rt::build_bvh(d->positions, n, all);
+        flat[0] = rt::flatten_bvh(s->host_bvh[0], d->positions);
+        s->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
+        // ---- shading records in scene-BVH order
+        attrs.resize(flat[0].tris.size());
+        for (size_t k = 0; k < attrs.size(); ++k) {
+            const uint32_t t = flat[0].tris[k].prim;
+            DevAttr &a = attrs[k];
+            std::memset(&a, 0, sizeof(a));
+            std::memcpy(a.n, d->normals + 9 * (size_t)t, 36);
+            std::memcpy(a.tg, d->tangents + 9 * (size_t)t, 36);
+            std::memcpy(a.uv, d->texcoords + 6 * (size_t)t, 24);
+            const DevTri &tr = flat[0].tris[k];
+            V3h c = cross_h({tr.v[0], tr.v[1], tr.v[2]}, {tr.u[0], tr.u[1], tr.u[2]}); // triangle::normal geometry.h:477-479
+            float l = len_h(c);
+            a.gn[0] = c.x / l;
+            a.gn[1] = c.y / l;
+            a.gn[2] = c.z / l;
+            a.material = d->material_ids[t];
+        }
     }
+    s->host_bvh[1] = rt::build_bvh(d->positions, n, lights);
+    flat[1] = rt::flatten_bvh(s->host_bvh[1], d->positions);
     std::vector<DevLightAux> laux(flat[1].tris.size());
     for (size_t k = 0; k < laux.size(); ++k) {
         const DevTri &tr = flat[1].tris[k];
@@ -402,6 +427,15 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
     int rc;
     for (int w = 0; w < 2; ++w) {
         DevBvh &b = w == 0 ? D.scene : D.lights;
+        if (w == 0 && dev_build) {
+            b.nodes = dbvh.nodes;
+            b.tris = dbvh.tris;
+            b.root = dbvh.root;
+            b.n_tris = dbvh.n_tris;
+            b.fast_ok = dbvh.fast_ok ? 1u : 0u;
+            s->dev_n_inner[0] = dbvh.n_inner;
+            continue;
+        }
         if ((rc = upload(flat[w].nodes, &b.nodes, s->owned)) != RT_OK)
             return rc;
         if ((rc = upload(flat[w].tris, &b.tris, s->owned)) != RT_OK)
@@ -409,8 +443,11 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
         b.root = flat[w].root;
         b.n_tris = (uint32_t)flat[w].tris.size();
         b.fast_ok = flat[w].fast_ok ? 1u : 0u;
+        s->dev_n_inner[w] = (uint32_t)flat[w].nodes.size();
     }
-    if ((rc = upload(attrs, &D.attrs, s->owned)) != RT_OK)
+    if (dev_build)
+        D.attrs = dbvh.attrs;
+    else if ((rc = upload(attrs, &D.attrs, s->owned)) != RT_OK)
         return rc;
     if ((rc = upload(laux, &D.light_aux, s->owned)) != RT_OK)
         return rc;
@@ -436,7 +473,10 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
     D.ray_depth = d->ray_depth;
     for (int k = 0; k < 3; ++k) { // scene bounds for the ray-ordering key (root node box of the scene BVH)
         float lo = 0.f, hi = 1.f;
-        if (s->host_bvh[0].root != RT_NONE && !s->host_bvh[0].nodes.empty()) {
+        if (dev_build) {
+            lo = dbvh.lo[k];
+            hi = dbvh.hi[k];
+        } else if (s->host_bvh[0].root != RT_NONE && !s->host_bvh[0].nodes.empty()) {
             lo = s->host_bvh[0].nodes[s->host_bvh[0].root].lo[k];
             hi = s->host_bvh[0].nodes[s->host_bvh[0].root].hi[k];
         }
@@ -812,12 +852,137 @@ extern "C" int rt_light_pdf(rt_scene *s, const float *rays, uint32_t n, float *p
     return rc;
 }
 
+extern "C" int rt_bvh_device_dump(rt_scene *s, int which, uint32_t *n_inner, uint32_t *n_tris, uint32_t *root, uint32_t *nodes64, uint32_t *tris48) {
+    if (!s || which < 0 || which > 1)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_bvh_device_dump: bad argument");
+    if (s->group)
+        return rt_bvh_device_dump(rt::group_primary(s->group), which, n_inner, n_tris, root, nodes64, tris48);
+    const DevBvh &b = which == 0 ? s->dev.scene : s->dev.lights;
+    if (n_inner)
+        *n_inner = s->dev_n_inner[which];
+    if (n_tris)
+        *n_tris = b.n_tris;
+    if (root)
+        *root = b.root;
+    HIP_TRY(hipSetDevice(s->device));
+    if (nodes64 && s->dev_n_inner[which])
+        HIP_TRY(hipMemcpy(nodes64, b.nodes, sizeof(DevNode) * (size_t)s->dev_n_inner[which], hipMemcpyDeviceToHost));
+    if (tris48 && b.n_tris)
+        HIP_TRY(hipMemcpy(tris48, b.tris, sizeof(DevTri) * (size_t)b.n_tris, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_build_times(const rt_scene *s, double *build_ms, double *upload_ms) {
+    if (!s)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_build_times: null argument");
+    if (s->group)
+        return rt_build_times(rt::group_primary(s->group), build_ms, upload_ms);
+    if (build_ms)
+        *build_ms = s->build_ms;
+    if (upload_ms)
+        *upload_ms = s->build_upload_ms;
+    return RT_OK;
+}
+
+// A device-built scene BVH has no host copy: rebuild the reference-style description (pre-order nodes with their OWN box,
+// bvh.h:157-163) from what is in HBM, once, when a caller asks for it.
+static int reconstruct_host_bvh(rt_scene *s) {
+    const uint32_t n_inner = s->dev_n_inner[0], n_tris = s->dev.scene.n_tris;
+    std::vector<DevNode> nodes(n_inner);
+    std::vector<DevTri> tris(n_tris);
+    HIP_TRY(hipSetDevice(s->device));
+    if (n_inner)
+        HIP_TRY(hipMemcpy(nodes.data(), s->dev.scene.nodes, sizeof(DevNode) * (size_t)n_inner, hipMemcpyDeviceToHost));
+    if (n_tris)
+        HIP_TRY(hipMemcpy(tris.data(), s->dev.scene.tris, sizeof(DevTri) * (size_t)n_tris, hipMemcpyDeviceToHost));
+    rt::HostBvh &hb = s->host_bvh[0];
+    hb.nodes.clear();
+    hb.order.resize(n_tris);
+    for (uint32_t k = 0; k < n_tris; ++k)
+        hb.order[k] = tris[k].prim;
+    hb.root = RT_NONE;
+    if (s->dev.scene.root == RT_NONE)
+        return RT_OK;
+    struct Item {
+        uint32_t ref, parent, side; // side: 0 root, 1 left, 2 right
+        float lo[3], hi[3];
+    };
+    auto leaf_range = [&](uint32_t ref, uint32_t &b, uint32_t &e) {
+        b = ref & RT_LEAF_BEGIN_MASK;
+        const uint32_t cnt = RT_LEAF_CNT(ref);
+        e = b + cnt;
+        if (cnt == 0) // big leaf: walk the per-triangle flags
+            for (e = b; e < n_tris && !(tris[e].flags & 1u); ++e) {
+            }
+        if (cnt == 0 && e < n_tris)
+            ++e;
+    };
+    std::vector<Item> stack;
+    Item r{};
+    r.ref = s->dev.scene.root;
+    r.parent = RT_NONE;
+    for (int c = 0; c < 3; ++c) { // the root's own box is stored nowhere: union of its children's (or of its triangles)
+        r.lo[c] = INFINITY;
+        r.hi[c] = -INFINITY;
+    }
+    if (r.ref & RT_LEAF_FLAG) {
+        uint32_t b, e;
+        leaf_range(r.ref, b, e);
+        for (uint32_t k = b; k < e; ++k)
+            for (int v = 0; v < 3; ++v)
+                for (int c = 0; c < 3; ++c) {
+                    const float x = v == 0 ? tris[k].a[c] : (v == 1 ? tris[k].a[c] + tris[k].v[c] : tris[k].a[c] + tris[k].u[c]);
+                    r.lo[c] = std::min(r.lo[c], x);
+                    r.hi[c] = std::max(r.hi[c], x);
+                }
+    } else {
+        const DevNode &nd = nodes[r.ref];
+        for (int c = 0; c < 3; ++c) {
+            r.lo[c] = std::min(nd.lmin[c], nd.rmin[c]);
+            r.hi[c] = std::max(nd.lmax[c], nd.rmax[c]);
+        }
+    }
+    stack.push_back(r);
+    while (!stack.empty()) {
+        const Item it = stack.back();
+        stack.pop_back();
+        const uint32_t idx = (uint32_t)hb.nodes.size();
+        rt::HostNode hn{};
+        std::memcpy(hn.lo, it.lo, 12);
+        std::memcpy(hn.hi, it.hi, 12);
+        hn.left = hn.right = RT_NONE;
+        if (it.parent != RT_NONE)
+            (it.side == 1 ? hb.nodes[it.parent].left : hb.nodes[it.parent].right) = idx;
+        if (it.ref & RT_LEAF_FLAG) {
+            leaf_range(it.ref, hn.obj_begin, hn.obj_end);
+            hb.nodes.push_back(hn);
+            continue;
+        }
+        hb.nodes.push_back(hn);
+        const DevNode &nd = nodes[it.ref];
+        Item l{}, rr{};
+        l.ref = nd.left, l.parent = idx, l.side = 1;
+        rr.ref = nd.right, rr.parent = idx, rr.side = 2;
+        std::memcpy(l.lo, nd.lmin, 12);
+        std::memcpy(l.hi, nd.lmax, 12);
+        std::memcpy(rr.lo, nd.rmin, 12);
+        std::memcpy(rr.hi, nd.rmax, 12);
+        stack.push_back(rr); // pre-order: left subtree first
+        stack.push_back(l);
+    }
+    hb.root = 0;
+    return RT_OK;
+}
+
 extern "C" int rt_bvh_info(rt_scene *s, int which, uint32_t *n_nodes, uint32_t *n_objects, uint32_t *root, uint32_t *nodes_out,
                            uint32_t *order_out) {
     if (!s || which < 0 || which > 1)
         return rt::fail(RT_ERR_INVALID_ARG, "rt_bvh_info: bad argument");
     if (s->group)
         return rt_bvh_info(rt::group_primary(s->group), which, n_nodes, n_objects, root, nodes_out, order_out);
+    if (which == 0 && s->device_built && s->host_bvh[0].nodes.empty() && s->dev.scene.n_tris)
+        if (int rc = reconstruct_host_bvh(s); rc != RT_OK)
+            return rc;
     const rt::HostBvh &b = s->host_bvh[which];
     if (n_nodes)
         *n_nodes = (uint32_t)b.nodes.size();

@@ -78,4 +78,17 @@ def test_s10m_full_size_parity_and_properties(gpu, oracle, sg):
     assert np.array_equal(b.view(np.uint32), a.view(np.uint32))
     img, _ = dev.run_raytracer_rgb8(W, H, 2, seed=11)
     assert np.array_equal(img, gpu.tonemap(a))
+    # ---- the device LBVH builder on the same 10^7 triangles: same closest hits, build time side by side
+    lb = gpu.DeviceScene(sc, device_bvh=True)
+    rays = random_rays(sc, 100_000, seed=78)
+    ap, ab = dev.cast_rays(rays)
+    bp, bb = lb.cast_rays(rays)
+    assert np.array_equal(ab[:, 2].view(np.uint32), bb[:, 2].view(np.uint32)) and (ap == bp).mean() > 0.995
+    c, cst = lb.run_raytracer(W, H, 2, seed=11)
+    assert np.isfinite(c).all() and float((a != c).any(axis=2).mean()) < 0.02
+    _, rst = dev.run_raytracer(W, H, 2, seed=11)
+    t_ref, t_dev = dev.build_times(), lb.build_times()
+    print(f"\n[S-10M] host reference-topology build {t_ref['build_ms'] / 1e3:.2f} s; device LBVH build {t_dev['build_ms']:.1f} ms (+ upload {t_dev['upload_ms']:.0f} ms); "
+          f"render 2 SPP: reference tree {rst['kernel_ms']:.0f} ms, LBVH {cst['kernel_ms']:.0f} ms")
+    lb.close()
     dev.close()
