@@ -305,7 +305,6 @@ template <int LDS_DEPTH> struct StackMemT {
             lds[(1 * LDS_DEPTH + sp) * 256] = __float_as_uint(d);
             lds[(2 * LDS_DEPTH + sp) * 256] = __float_as_uint(loc);
         } else {
-            DIAG(28, (unsigned long long)__popcll(__ballot(1)));
             ov_ref[sp - LDS_DEPTH] = ref;
             ov_d[sp - LDS_DEPTH] = d;
             ov_loc[sp - LDS_DEPTH] = loc;
@@ -354,6 +353,83 @@ template <int LDS_DEPTH> struct StackMemT {
         return ref;
     }
 };
+// The same stack for wf_extend, where deep traversals are the norm (S-10M: a tree ~24 levels deep keeps 8-12 deferred
+// siblings pending): the LDS part is a RING that always holds the NEWEST frames. Memory position p (0 = oldest) lives in
+// LDS slot p % LDS_DEPTH while p >= base, and in scratch once it has been evicted (p < base). A push into a full ring evicts
+// the OLDEST LDS frame to scratch; a pop that finds the ring empty takes one frame back from scratch. Scratch is touched only
+// when the depth wanders further than LDS_DEPTH from where it was — with StackMemT's fixed split (positions >= LDS_DEPTH
+// always in scratch) every push and pop beyond depth 7 went to scratch: 1.2 scratch pushes per cast on S-sponza, 9x HBM
+// write amplification, and a scratch-load stall in about every second unwind iteration (profiles/r02_write_amp.txt).
+template <int LDS_DEPTH> struct RingStackT {
+    uint32_t *lds; // [3][LDS_DEPTH][256] dwords, this thread's column starts at lds + threadIdx.x
+    uint32_t *ov_ref; // [RT_MAX_STACK], per-lane scratch, indexed by memory position
+    float *ov_d;
+    float *ov_loc;
+    int base; // positions [base, newest] are in LDS
+    DEV static uint32_t slot_of(uint32_t pos) { // pos % LDS_DEPTH for pos < 64
+        if constexpr (LDS_DEPTH == 8)
+            return pos & 7u;
+        else if constexpr (LDS_DEPTH == 4)
+            return pos & 3u;
+        else
+            return pos - (uint32_t)LDS_DEPTH * ((pos * (uint32_t)((256 + LDS_DEPTH - 1) / LDS_DEPTH)) >> 8);
+    }
+    DEV void reset() { base = 0; }
+    DEV void push(int pos, uint32_t ref, float d, float loc) {
+        const uint32_t slot = slot_of((uint32_t)pos);
+        if (pos - base == LDS_DEPTH) { // ring full: the slot about to be overwritten holds position `base`, the oldest
+            DIAG(28, (unsigned long long)__popcll(__ballot(1)));
+            ov_ref[base] = lds[(0 * LDS_DEPTH + slot) * 256];
+            ov_d[base] = __uint_as_float(lds[(1 * LDS_DEPTH + slot) * 256]);
+            ov_loc[base] = __uint_as_float(lds[(2 * LDS_DEPTH + slot) * 256]);
+            ++base;
+        }
+        lds[(0 * LDS_DEPTH + slot) * 256] = ref;
+        lds[(1 * LDS_DEPTH + slot) * 256] = __float_as_uint(d);
+        lds[(2 * LDS_DEPTH + slot) * 256] = __float_as_uint(loc);
+    }
+    DEV void pop(int pos, uint32_t &ref, float &d, float &loc) {
+        const uint32_t slot = slot_of((uint32_t)pos);
+        ref = lds[(0 * LDS_DEPTH + slot) * 256];
+        d = __uint_as_float(lds[(1 * LDS_DEPTH + slot) * 256]);
+        loc = __uint_as_float(lds[(2 * LDS_DEPTH + slot) * 256]);
+        if (pos < base) { // the ring is empty: take the frame back from scratch
+            ref = ov_ref[pos];
+            d = ov_d[pos];
+            loc = ov_loc[pos];
+            base = pos;
+        }
+    }
+    // pop() inside straight-line wave code: every lane reads some valid LDS slot (pos may be negative or stale on lanes
+    // that do not `want` the frame), only wanting lanes look at scratch
+    DEV void pop_masked(int pos, bool want, uint32_t &ref, float &d, float &loc) {
+        const uint32_t p = (uint32_t)pos < (uint32_t)RT_MAX_STACK ? (uint32_t)pos : 0u;
+        const uint32_t slot = slot_of(p);
+        ref = lds[(0 * LDS_DEPTH + slot) * 256];
+        d = __uint_as_float(lds[(1 * LDS_DEPTH + slot) * 256]);
+        loc = __uint_as_float(lds[(2 * LDS_DEPTH + slot) * 256]);
+        // keep the LDS reads where they are: sunk into the branch below they would merge with the scratch loads into
+        // generic flat_loads of a selected pointer
+        asm volatile("" : "+v"(ref), "+v"(d), "+v"(loc));
+        if (want && pos < base) {
+            ref = ov_ref[pos];
+            d = ov_d[pos];
+            loc = ov_loc[pos];
+            base = pos;
+        }
+    }
+};
+#define RT_DECLARE_RING_STACK(NAME, DEPTH, SHARED_ARRAY) \
+    uint32_t NAME##_ov_ref[RT_MAX_STACK];               \
+    float NAME##_ov_d[RT_MAX_STACK];                    \
+    float NAME##_ov_loc[RT_MAX_STACK];                  \
+    RingStackT<(DEPTH)> NAME;                           \
+    NAME.lds = (SHARED_ARRAY) + threadIdx.x;            \
+    NAME.ov_ref = NAME##_ov_ref;                        \
+    NAME.ov_d = NAME##_ov_d;                            \
+    NAME.ov_loc = NAME##_ov_loc;                        \
+    NAME.base = 0
+
 #define STACK_LDS_DWORDS (3 * LDS_DEPTH * 256)
 #define STACK_LDS_DWORDS_FOR(depth) (3 * (depth) * 256)
 #define RT_DECLARE_STACK(NAME, DEPTH, SHARED_ARRAY)          \
@@ -393,6 +469,23 @@ DEV bool ray_fast_ok(const DevBvh &bvh, V3 o, V3 d) {
     const float hi = fmaxf(fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
     return (bvh.fast_ok != 0u) & (d.x == d.x) & (d.y == d.y) & (d.z == d.z) & (lo >= RANGE_LO) & (hi <= RANGE_HI) & coord_in_fast_range(o.x) &
            coord_in_fast_range(o.y) & coord_in_fast_range(o.z);
+}
+// the per-ray half alone (stored with a queued ray, WfPath::fast) and the start of a traversal from stored values
+DEV bool ray_fast_ok_ray(V3 o, V3 d) {
+    const float lo = fminf(fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    const float hi = fmaxf(fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    return (d.x == d.x) & (d.y == d.y) & (d.z == d.z) & (lo >= RANGE_LO) & (hi <= RANGE_HI) & coord_in_fast_range(o.x) & coord_in_fast_range(o.y) &
+           coord_in_fast_range(o.z);
+}
+DEV void trav_init_stored(Trav &T, const DevBvh &bvh, V3 o, V3 d, V3 r, bool ray_ok) {
+    T.o = o;
+    T.d = d;
+    T.r = r;
+    T.fast = ray_ok & (bvh.fast_ok != 0u);
+    T.cur = (bvh.root == RT_NONE || bvh.n_tris == 0) ? T_DONE : bvh.root;
+    T.sp = 0;
+    T.t_loc = RT_NAN;
+    T.best = Hit{RT_NONE, 0.f, 0.f, 0.f};
 }
 DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
     T.o = o;

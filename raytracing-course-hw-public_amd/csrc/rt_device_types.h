@@ -119,8 +119,8 @@ struct DevStats { // device-side counters, see rt_stats in include/rt_abi.h
 };
 
 // ---- wavefront pipeline (rt_wavefront.hip): path = one (pixel, sample); queues hold live paths between bounces
-// Queue record, one per live path (64 B = one HBM request): the ray (first 32 B: all wf_extend and wf_sort_keys read) and
-// the path's RNG state (next 16 B). The state of a path travels WITH its ray through the queues, so wf_shade finds ray
+// Queue record, one per live path (64 B = one HBM request): the ray (first 32 B), what wf_extend needs to start its traversal
+// without arithmetic (next 16 B) and the path's RNG state (last 16 B). The state of a path travels WITH its ray through the queues, so wf_shade finds ray
 // and state with one gather and writes both with the coalesced queue traffic instead of a random per-path record.
 struct alignas(64) WfPath {
     float o[3];
@@ -128,8 +128,9 @@ struct alignas(64) WfPath {
     float dy, dz;
     uint32_t path;  // path id within the pass = index into fold / sample_out
     uint32_t depth; // low 16 bits: remaining trace_ray budget (raytracer.h:596); high 16 bits: pending shade() frames
+    float r[3];     // 1 / d, IEEE division, computed where the ray is made (wf_generate / wf_shade are latency bound; wf_extend,
+    uint32_t fast;  //   the issue-bound kernel, just loads it) + the per-ray half of div_exact_fast's preconditions
     uint32_t s[4];  // xoshiro128++ state
-    uint32_t pad[4];
 };
 static_assert(sizeof(WfPath) == 64, "WfPath must be 64 bytes");
 struct alignas(16) WfHit { // 16 B: closest hit of the ray in the same queue slot

@@ -38,7 +38,7 @@ namespace {
 #ifndef RT_EXT_LDS_DEPTH
 #define RT_EXT_LDS_DEPTH 6 /* LDS part of the traversal stack in wf_extend: 6 -> 26 KB/block -> 6 blocks (24 waves) per CU */
 #endif
-using ExtStack = StackMemT<RT_EXT_LDS_DEPTH>;
+using ExtStack = RingStackT<RT_EXT_LDS_DEPTH>;
 #ifndef RT_SHADE_WAVES_PER_SIMD
 #define RT_SHADE_WAVES_PER_SIMD 4
 #endif
@@ -81,7 +81,8 @@ template <bool STATS> __global__ __launch_bounds__(256) void wf_generate(const D
         float4 *rq = reinterpret_cast<float4 *>(L.paths_in + i);
         rq[0] = make_float4(cam_pos.x, cam_pos.y, cam_pos.z, rd.x);
         rq[1] = make_float4(rd.y, rd.z, __uint_as_float(i), __uint_as_float(L.ray_depth)); // path id; full budget, no pending frames
-        *reinterpret_cast<uint4 *>(rq + 2) = make_uint4(rng.g.s[0], rng.g.s[1], rng.g.s[2], rng.g.s[3]);
+        rq[2] = make_float4(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z, __uint_as_float(ray_fast_ok_ray(cam_pos, rd) ? 1u : 0u));
+        *reinterpret_cast<uint4 *>(rq + 3) = make_uint4(rng.g.s[0], rng.g.s[1], rng.g.s[2], rng.g.s[3]);
         st.cast(); // ray_depth >= 1: trace_ray casts (raytracer.h:600)
     }
     st.flush(L.stats);
@@ -186,7 +187,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
     unsigned long long *s_min = s_min_all[wave];
     float2 *s_bc = s_bc_all[wave];
     LaneStats<STATS> st;
-    RT_DECLARE_STACK(stk, RT_EXT_LDS_DEPTH, s_stack);
+    RT_DECLARE_RING_STACK(stk, RT_EXT_LDS_DEPTH, s_stack);
 #ifdef RT_DIAG
     if (STATS && threadIdx.x == 0 && blockIdx.x == 0)
         g_diag = (DevStats *)L.diag;
@@ -234,9 +235,10 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
                 const uint32_t jq = q_lo + rank;
                 const uint32_t j = L.order ? L.order[jq] : jq; // coherence-sorted processing order
                 const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
-                const float4 r0 = rq[0], r1 = rq[1];
+                const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
                 slot = jq; // the hit goes to the queue POSITION (see WfLaunch::hits)
-                trav_init(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y));
+                trav_init_stored(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r2.x, r2.y, r2.z), __float_as_uint(r2.w) != 0u);
+                stk.reset();
                 if (T.cur == T_DONE) // no geometry at all: immediate miss
                     *reinterpret_cast<float4 *>(L.hits + jq) = make_float4(__uint_as_float(RT_NONE), 0.f, 0.f, 0.f);
             }
@@ -331,13 +333,13 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
         const uint32_t jq = base + threadIdx.x; // queue position: where wf_extend left this ray's hit
         const bool active = jq < n_in;
         bool survive = false;
-        float4 nr0 = make_float4(0.f, 0.f, 0.f, 0.f), nr1 = nr0;
+        float4 nr0 = make_float4(0.f, 0.f, 0.f, 0.f), nr1 = nr0, nr2 = nr0;
         uint4 nrng = make_uint4(0u, 0u, 0u, 0u);
         if (active) {
             const uint32_t j = L.order ? L.order[jq] : jq;
             const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
             const float4 r0 = rq[0], r1 = rq[1];
-            const uint4 p0 = *reinterpret_cast<const uint4 *>(rq + 2);
+            const uint4 p0 = *reinterpret_cast<const uint4 *>(rq + 3);
             const float4 hq = *reinterpret_cast<const float4 *>(L.hits + jq);
             const uint32_t path = __float_as_uint(r1.z);
             Rng<RT_RNG_DEVICE> rng;
@@ -382,6 +384,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
                 st.cast();
                 nr0 = make_float4(sr.nro.x, sr.nro.y, sr.nro.z, sr.nrd.x);
                 nr1 = make_float4(sr.nrd.y, sr.nrd.z, __uint_as_float(path), __uint_as_float(depth_left | (nb << 16)));
+                nr2 = make_float4(1.0f / sr.nrd.x, 1.0f / sr.nrd.y, 1.0f / sr.nrd.z, __uint_as_float(ray_fast_ok_ray(sr.nro, sr.nrd) ? 1u : 0u));
                 nrng = make_uint4(rng.g.s[0], rng.g.s[1], rng.g.s[2], rng.g.s[3]);
             }
         }
@@ -398,7 +401,8 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
                 float4 *rw = reinterpret_cast<float4 *>(L.paths_out + obase + rank);
                 rw[0] = nr0;
                 rw[1] = nr1;
-                *reinterpret_cast<uint4 *>(rw + 2) = nrng;
+                rw[2] = nr2;
+                *reinterpret_cast<uint4 *>(rw + 3) = nrng;
             }
         }
     }

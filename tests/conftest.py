@@ -12,6 +12,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # torch (used by a few tests for device buffers / torch.distributed) bundles its own HIP runtime: it must be loaded BEFORE
+    import torch  # noqa: F401  librt_amd.so, or the process ends up with two runtimes and torch sees no GPU (same rule as bench.py)
+except ImportError:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
