@@ -8,6 +8,8 @@
 //   ref_probe primary  <gltf> <W> <H> <out.bin>            closest hits of pixel-centre rays gen_ray(camera,x,y)
 //   ref_probe lightpdf <gltf> <W> <H> <rays.bin> <out.bin> bvh_mix_dist::pdf for explicit (x, dir) pairs
 //   ref_probe scene    <gltf> <W> <H> <out.bin>            flattened scene.objects (positions/normals/uv/tangents)
+//   ref_probe texture  <image> 0 0 <out.bin>               geometry::Texture::load_img (the reference's stb_image build, 4 channels
+//                                                          forced, geometry.h:584-598): [width, height, texel floats r g b a ...]
 //
 // Binary formats are little-endian u32/f32 arrays described next to each writer.
 #define STB_IMAGE_IMPLEMENTATION
@@ -44,6 +46,22 @@ int main(int argc, char **argv) {
         return 2;
     }
     std::string mode = argv[1];
+    if (mode == "texture") { // no scene involved: what the reference's image decoder returns for one file
+        std::vector<uint32_t> o;
+        try {
+            geometry::Texture t = geometry::Texture::load_img(argv[2]);
+            put_u32(o, t.width);
+            put_u32(o, t.height);
+            for (const auto &c : t.data)
+                for (int k = 0; k < 4; ++k)
+                    put_f32(o, c.val[k]);
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "texture: %s\n", e.what());
+            return 1;
+        }
+        write_words(argv[5], o);
+        return 0;
+    }
     unsigned width = std::strtol(argv[3], nullptr, 10);
     unsigned height = std::strtol(argv[4], nullptr, 10);
     Scene scene = parse_gltf_scene(std::filesystem::path(argv[2]), static_cast<float>(width) / height);

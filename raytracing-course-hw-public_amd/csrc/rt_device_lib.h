@@ -372,7 +372,16 @@ template <int LDS_DEPTH> struct RingStackT {
         else if constexpr (LDS_DEPTH == 4)
             return pos & 3u;
         else
-            return pos - (uint32_t)LDS_DEPTH * ((pos * (uint32_t)((256 + LDS_DEPTH - 1) / LDS_DEPTH)) >> 8);
+        {
+            // pos / LDS_DEPTH by a full-rate 24-bit multiply (a 32-bit v_mul_lo_u32, which the compiler picks for a plain
+            // `*` here, issues at quarter rate), then pos - LDS_DEPTH * q with shifts and adds
+            uint32_t q;
+            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(q) : "v"(pos), "v"((uint32_t)((256 + LDS_DEPTH - 1) / LDS_DEPTH)));
+            q >>= 8;
+            static_assert(LDS_DEPTH == 6 || LDS_DEPTH == 5 || LDS_DEPTH == 12 || LDS_DEPTH == 3, "add the shift/add form of LDS_DEPTH * q");
+            const uint32_t m = LDS_DEPTH == 6 ? (q << 2) + (q << 1) : LDS_DEPTH == 5 ? (q << 2) + q : LDS_DEPTH == 12 ? (q << 3) + (q << 2) : (q << 1) + q;
+            return pos - m;
+        }
     }
     DEV void reset() { base = 0; }
     DEV void push(int pos, uint32_t ref, float d, float loc) {
