@@ -629,28 +629,30 @@ template <bool STATS, class STK> DEV void trav_step_inner_fast(Trav &T, const De
     T.t_loc = both ? RT_NAN : T.t_loc;
     T.cur = both ? (swap ? right : left) : (hl ? left : (hr ? right : T_POP));
 }
-template <class STK> DEV void trav_pop_wave(Trav &T, STK &stk) {
-    while (__ballot(T.cur == T_POP) != 0ull) {
-        DIAG(7, 1);
-        DIAG(27, (unsigned long long)__popcll(__ballot(T.cur == T_POP)));
-        const bool pop = T.cur == T_POP;
-        const bool go = pop & (T.sp != 0);
-        const int nsp = T.sp - 1;
-        const bool refill = go & (nsp > 0);
-        uint32_t n_ref;
-        float n_d, n_loc;
-        stk.pop_masked(nsp - 1, refill, n_ref, n_d, n_loc);
-        const float t_near = T.t_loc;
-        const bool visit = !(t_near <= T.top_d); // !has || t_near > d_far (bvh.h:221)
-        T.cur = pop ? (go ? (visit ? T.top_ref : T_POP) : T_DONE) : T.cur;
-        T.t_loc = go ? fminf(T.top_loc, t_near) : t_near;
-        T.sp = go ? nsp : T.sp;
-        T.top_ref = refill ? n_ref : T.top_ref;
-        T.top_d = refill ? n_d : T.top_d;
-        T.top_loc = refill ? n_loc : T.top_loc;
-    }
+// one unwind step for every lane in T_POP, as straight-line wave code (lanes in other states pass through unchanged)
+template <class STK> DEV void trav_pop_once(Trav &T, STK &stk) {
+    DIAG(7, 1);
+    DIAG(27, (unsigned long long)__popcll(__ballot(T.cur == T_POP)));
+    const bool pop = T.cur == T_POP;
+    const bool go = pop & (T.sp != 0);
+    const int nsp = T.sp - 1;
+    const bool refill = go & (nsp > 0);
+    uint32_t n_ref;
+    float n_d, n_loc;
+    stk.pop_masked(nsp - 1, refill, n_ref, n_d, n_loc);
+    const float t_near = T.t_loc;
+    const bool visit = !(t_near <= T.top_d); // !has || t_near > d_far (bvh.h:221)
+    T.cur = pop ? (go ? (visit ? T.top_ref : T_POP) : T_DONE) : T.cur;
+    T.t_loc = go ? fminf(T.top_loc, t_near) : t_near;
+    T.sp = go ? nsp : T.sp;
+    T.top_ref = refill ? n_ref : T.top_ref;
+    T.top_d = refill ? n_d : T.top_d;
+    T.top_loc = refill ? n_loc : T.top_loc;
 }
-
+template <class STK> DEV void trav_pop_wave(Trav &T, STK &stk) {
+    while (__ballot(T.cur == T_POP) != 0ull)
+        trav_pop_once(T, stk);
+}
 // bvh_mix_dist::pdf (raytracer.h:363-375) = BVH::foreach_intersection (bvh.h:237-260) over the light BVH summing
 // triangle_dist::pdf_at (raytracer.h:255-261) in DFS order (node objects, left subtree, right subtree).
 template <bool STATS, class STK> DEV float lights_pdf(const DevScene &S, V3 x, V3 d, STK &stk, LaneStats<STATS> &st) {

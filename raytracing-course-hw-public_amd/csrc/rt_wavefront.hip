@@ -46,11 +46,14 @@ using ExtStack = RingStackT<RT_EXT_LDS_DEPTH>;
 #define RT_SHADE_LDS_DEPTH 4 /* only the light-BVH traversal of bvh_mix_dist::pdf uses a stack in wf_shade */
 #endif
 using ShadeStack = StackMemT<RT_SHADE_LDS_DEPTH>;
+#ifndef RT_EXT_POP_ONCE
+#define RT_EXT_POP_ONCE 1 /* bounded unwind: one stack pop per trip instead of an inner loop until no lane unwinds */
+#endif
 #ifndef RT_EXT_CHUNK
 #define RT_EXT_CHUNK 128u /* queue positions a wave takes per ticket atomic */
 #endif
 #ifndef RT_EXT_REFILL_MIN
-#define RT_EXT_REFILL_MIN 24 /* refill a wave's idle lanes once this many have finished (a refill stalls the wave on the ray loads) */
+#define RT_EXT_REFILL_MIN 16 /* refill a wave's idle lanes once this many have finished (a refill stalls the wave on the ray loads) */
 #endif
 
 DEV uint32_t wf_global_pixel(const WfLaunch &L, uint32_t local_pixel) {
@@ -246,6 +249,31 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
         }
         DIAG(12, 1);
         DG_STAMP(dg_refill);
+#if RT_EXT_POP_ONCE
+        // Bounded unwind: ONE stack pop per trip for every lane that has to unwind (a lane whose pop ends in a pruned far
+        // child pops again next trip and sits out one node step: ~1 in 5 unwinding lanes). The unwind used to be a loop that
+        // ran until no lane of the wave was left in T_POP: 1.2 iterations per trip at ~7 of 64 lanes, each a full LDS round
+        // trip, plus the loop's own header and exit code — 22 % of the kernel's wave cycles (profiles/r02_extend_sections.txt).
+        // (Tried and not kept: issuing the pop's LDS reads here and consuming them only behind the node fetch — 3 more live
+        // VGPRs and the extra predicate traffic cost more than the hidden LDS round trip: 233.7 vs 238.5 Msamples/s.)
+        const bool was_live = T.cur != T_DONE;
+        trav_pop_once(T, stk);
+        if (was_live && T.cur == T_DONE)
+            *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
+        DG_STAMP(dg_pop);
+        const bool active = T.cur != T_DONE;
+        const bool popping = T.cur == T_POP; // note: T_POP has the leaf bit set, it must be told apart first
+        const bool at_leaf = active && !popping && (T.cur & RT_LEAF_FLAG) != 0 && RT_LEAF_CNT(T.cur) != 0;
+        const bool stepper = active && !popping && !at_leaf; // inner node, or a big leaf walked triangle by triangle
+        const unsigned long long lm = __ballot(at_leaf), sm = __ballot(stepper);
+        if ((lm | sm) == 0ull) {
+            if (__ballot(popping) != 0ull)
+                continue; // only unwinding lanes left: pop again
+            if (exhausted)
+                break;
+            continue;
+        }
+#else
         const bool active = T.cur != T_DONE;
         const bool at_leaf = active && (T.cur & RT_LEAF_FLAG) != 0 && RT_LEAF_CNT(T.cur) != 0;
         const bool stepper = active && !at_leaf; // inner node, or a big leaf walked triangle by triangle
@@ -255,6 +283,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
                 break;
             continue;
         }
+#endif
         if (sm == 0ull || __popcll(lm) >= RT_EXT_LEAF_MIN) {
             leaf_batch<STATS>(T, S.scene, at_leaf, s_owner, s_min, s_bc, st);
             DG_STAMP(dg_leaf);
@@ -273,11 +302,13 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
             }
             DG_STAMP(dg_node);
         }
+#if !RT_EXT_POP_ONCE
         trav_pop_wave(T, stk); // unwind after a leaf batch or a node step, all lanes of the wave together
         DG_STAMP(dg_pop);
         if (active && T.cur == T_DONE)
             *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
         DG_STAMP(dg_store);
+#endif
     }
 #ifdef RT_DIAG_CYCLES
     if ((threadIdx.x & 63u) == 0u && L.diag) {
