@@ -358,27 +358,29 @@ template <int LDS_DEPTH> struct StackMemT {
 // LDS slot p % LDS_DEPTH while p >= base, and in scratch once it has been evicted (p < base). A push into a full ring evicts
 // the OLDEST LDS frame to scratch; a pop that finds the ring empty takes one frame back from scratch. Scratch is touched only
 // when the depth wanders further than LDS_DEPTH from where it was — with StackMemT's fixed split (positions >= LDS_DEPTH
-// always in scratch) every push and pop beyond depth 7 went to scratch: 1.2 scratch pushes per cast on S-sponza, 9x HBM
-// write amplification, and a scratch-load stall in about every second unwind iteration (profiles/r02_write_amp.txt).
+// always in scratch) every push and pop beyond depth 7 went to scratch: 1.2 scratch pushes per cast on S-sponza (0.65 with
+// the ring), 9x HBM write amplification of the kernel's real output, the hit records (profiles/r02_write_amp.txt).
 template <int LDS_DEPTH> struct RingStackT {
     uint32_t *lds; // [3][LDS_DEPTH][256] dwords, this thread's column starts at lds + threadIdx.x
-    uint32_t *ov_ref; // [RT_MAX_STACK], per-lane scratch, indexed by memory position
-    float *ov_d;
-    float *ov_loc;
-    int base; // positions [base, newest] are in LDS
+    // Evicted frames go to a global workspace, one 16-byte record {ref, d_far, saved local best, -} per (position, thread),
+    // laid out [position][thread of the grid]: an eviction or a refill is ONE 16-byte access (the three per-lane scratch
+    // arrays this replaces cost three 4-byte accesses in three different 256-byte rows, i.e. three 32-byte sector writes
+    // once the lines left L2), and neighbouring lanes' records of one position share lines.
+    uint4 *ov;      // this thread's record of position 0
+    uint32_t stride; // records per position = threads of the grid
+    int base;       // positions [base, newest] are in LDS
     DEV static uint32_t slot_of(uint32_t pos) { // pos % LDS_DEPTH for pos < 64
         if constexpr (LDS_DEPTH == 8)
             return pos & 7u;
         else if constexpr (LDS_DEPTH == 4)
             return pos & 3u;
-        else
-        {
+        else {
             // pos / LDS_DEPTH by a full-rate 24-bit multiply (a 32-bit v_mul_lo_u32, which the compiler picks for a plain
             // `*` here, issues at quarter rate), then pos - LDS_DEPTH * q with shifts and adds
             uint32_t q;
             asm("v_mul_u32_u24 %0, %1, %2" : "=v"(q) : "v"(pos), "v"((uint32_t)((256 + LDS_DEPTH - 1) / LDS_DEPTH)));
             q >>= 8;
-            static_assert(LDS_DEPTH == 6 || LDS_DEPTH == 5 || LDS_DEPTH == 12 || LDS_DEPTH == 3, "add the shift/add form of LDS_DEPTH * q");
+            static_assert(LDS_DEPTH == 6 || LDS_DEPTH == 5 || LDS_DEPTH == 12 || LDS_DEPTH == 3 || LDS_DEPTH == 8 || LDS_DEPTH == 4, "add the shift/add form of LDS_DEPTH * q");
             const uint32_t m = LDS_DEPTH == 6 ? (q << 2) + (q << 1) : LDS_DEPTH == 5 ? (q << 2) + q : LDS_DEPTH == 12 ? (q << 3) + (q << 2) : (q << 1) + q;
             return pos - m;
         }
@@ -388,9 +390,7 @@ template <int LDS_DEPTH> struct RingStackT {
         const uint32_t slot = slot_of((uint32_t)pos);
         if (pos - base == LDS_DEPTH) { // ring full: the slot about to be overwritten holds position `base`, the oldest
             DIAG(28, (unsigned long long)__popcll(__ballot(1)));
-            ov_ref[base] = lds[(0 * LDS_DEPTH + slot) * 256];
-            ov_d[base] = __uint_as_float(lds[(1 * LDS_DEPTH + slot) * 256]);
-            ov_loc[base] = __uint_as_float(lds[(2 * LDS_DEPTH + slot) * 256]);
+            ov[(size_t)base * stride] = make_uint4(lds[(0 * LDS_DEPTH + slot) * 256], lds[(1 * LDS_DEPTH + slot) * 256], lds[(2 * LDS_DEPTH + slot) * 256], 0u);
             ++base;
         }
         lds[(0 * LDS_DEPTH + slot) * 256] = ref;
@@ -402,41 +402,39 @@ template <int LDS_DEPTH> struct RingStackT {
         ref = lds[(0 * LDS_DEPTH + slot) * 256];
         d = __uint_as_float(lds[(1 * LDS_DEPTH + slot) * 256]);
         loc = __uint_as_float(lds[(2 * LDS_DEPTH + slot) * 256]);
-        if (pos < base) { // the ring is empty: take the frame back from scratch
-            ref = ov_ref[pos];
-            d = ov_d[pos];
-            loc = ov_loc[pos];
+        if (pos < base) { // the ring is empty: take the frame back from the workspace
+            const uint4 v = ov[(size_t)pos * stride];
+            ref = v.x;
+            d = __uint_as_float(v.y);
+            loc = __uint_as_float(v.z);
             base = pos;
         }
     }
     // pop() inside straight-line wave code: every lane reads some valid LDS slot (pos may be negative or stale on lanes
-    // that do not `want` the frame), only wanting lanes look at scratch
+    // that do not `want` the frame), only wanting lanes look at the workspace
     DEV void pop_masked(int pos, bool want, uint32_t &ref, float &d, float &loc) {
         const uint32_t p = (uint32_t)pos < (uint32_t)RT_MAX_STACK ? (uint32_t)pos : 0u;
         const uint32_t slot = slot_of(p);
         ref = lds[(0 * LDS_DEPTH + slot) * 256];
         d = __uint_as_float(lds[(1 * LDS_DEPTH + slot) * 256]);
         loc = __uint_as_float(lds[(2 * LDS_DEPTH + slot) * 256]);
-        // keep the LDS reads where they are: sunk into the branch below they would merge with the scratch loads into
+        // keep the LDS reads where they are: sunk into the branch below they would merge with the global loads into
         // generic flat_loads of a selected pointer
         asm volatile("" : "+v"(ref), "+v"(d), "+v"(loc));
         if (want && pos < base) {
-            ref = ov_ref[pos];
-            d = ov_d[pos];
-            loc = ov_loc[pos];
+            const uint4 v = ov[(size_t)pos * stride];
+            ref = v.x;
+            d = __uint_as_float(v.y);
+            loc = __uint_as_float(v.z);
             base = pos;
         }
     }
 };
-#define RT_DECLARE_RING_STACK(NAME, DEPTH, SHARED_ARRAY) \
-    uint32_t NAME##_ov_ref[RT_MAX_STACK];               \
-    float NAME##_ov_d[RT_MAX_STACK];                    \
-    float NAME##_ov_loc[RT_MAX_STACK];                  \
-    RingStackT<(DEPTH)> NAME;                           \
-    NAME.lds = (SHARED_ARRAY) + threadIdx.x;            \
-    NAME.ov_ref = NAME##_ov_ref;                        \
-    NAME.ov_d = NAME##_ov_d;                            \
-    NAME.ov_loc = NAME##_ov_loc;                        \
+#define RT_DECLARE_RING_STACK(NAME, DEPTH, SHARED_ARRAY, OVERFLOW, STRIDE)     \
+    RingStackT<(DEPTH)> NAME;                                                  \
+    NAME.lds = (SHARED_ARRAY) + threadIdx.x;                                   \
+    NAME.ov = (OVERFLOW) + ((size_t)blockIdx.x * blockDim.x + threadIdx.x);    \
+    NAME.stride = (STRIDE);                                                    \
     NAME.base = 0
 
 #define STACK_LDS_DWORDS (3 * LDS_DEPTH * 256)

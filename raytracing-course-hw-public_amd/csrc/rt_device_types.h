@@ -164,6 +164,8 @@ struct WfLaunch {
     RtF4 *sample_out;        // [n_paths]: sanitised radiance of each finished sample
     RtF4 *accum;             // [pass_pixels]: running per-pixel sum across sample passes (reference order)
     float *fb;               // width*height*3
+    void *stack_overflow;    // wf_extend's evicted traversal-stack frames: [RT_MAX_STACK][stack_stride] records of 16 B
+    uint32_t stack_stride;   // = threads of the wf_extend grid
     uint32_t *counters;      // WF_CNT_*
     void *diag;              // development census (-DRT_DIAG), 32 x u64, else unused
     const uint32_t *order;   // optional: position q processes queue slot order[q] (coherence sort; extend AND shade); null = identity

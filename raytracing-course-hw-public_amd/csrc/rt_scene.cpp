@@ -137,6 +137,8 @@ struct rt_scene {
     WfFold *wf_fold = nullptr;
     RtF4 *wf_samples = nullptr, *wf_accum = nullptr;
     uint32_t *wf_counters = nullptr;
+    void *wf_stack_overflow = nullptr; // wf_extend's evicted stack frames (RingStackT): RT_MAX_STACK x grid threads x 16 B
+    uint32_t wf_stack_stride = 0;
     uint32_t *wf_sort_keys[2] = {nullptr, nullptr}, *wf_sort_vals[2] = {nullptr, nullptr};
     void *wf_sort_temp = nullptr;
     size_t wf_sort_temp_bytes = 0;
@@ -163,6 +165,9 @@ struct rt_scene {
             (rc = alloc(paths * sizeof(WfHit), (void **)&wf_hits)) != RT_OK || (rc = alloc(paths * depth * sizeof(WfFold), (void **)&wf_fold)) != RT_OK ||
             (rc = alloc(paths * sizeof(RtF4), (void **)&wf_samples)) != RT_OK || (rc = alloc(pixels * sizeof(RtF4), (void **)&wf_accum)) != RT_OK ||
             (rc = alloc(WF_CNT_WORDS * sizeof(uint32_t) + 1024, (void **)&wf_counters)) != RT_OK)
+            return rc;
+        wf_stack_stride = (uint32_t)num_cus * 8u * 256u; // the wf_extend grid: 8 blocks of 256 threads per CU
+        if ((rc = alloc((size_t)RT_MAX_STACK * wf_stack_stride * 16, &wf_stack_overflow)) != RT_OK)
             return rc;
         wf_sort_temp_bytes = rt::wavefront_sort_temp_bytes(paths);
         if ((rc = alloc(paths * 4, (void **)&wf_sort_keys[0])) != RT_OK || (rc = alloc(paths * 4, (void **)&wf_sort_keys[1])) != RT_OK ||
@@ -679,6 +684,8 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
         W.accum = s->wf_accum;
         W.fb = d_fb;
         W.counters = s->wf_counters;
+        W.stack_overflow = s->wf_stack_overflow;
+        W.stack_stride = s->wf_stack_stride;
         W.diag = s->wf_counters + 64; // dev census words live behind the queue counters
         const char *sort_env = std::getenv("RT_WF_SORT");
         const bool sort_rays = sort_env ? std::atoi(sort_env) != 0 : true;

@@ -190,7 +190,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
     unsigned long long *s_min = s_min_all[wave];
     float2 *s_bc = s_bc_all[wave];
     LaneStats<STATS> st;
-    RT_DECLARE_RING_STACK(stk, RT_EXT_LDS_DEPTH, s_stack);
+    RT_DECLARE_RING_STACK(stk, RT_EXT_LDS_DEPTH, s_stack, reinterpret_cast<uint4 *>(L.stack_overflow), L.stack_stride);
 #ifdef RT_DIAG
     if (STATS && threadIdx.x == 0 && blockIdx.x == 0)
         g_diag = (DevStats *)L.diag;
@@ -533,7 +533,7 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         WF_LAUNCH((wf_generate<true>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
     else
         WF_LAUNCH((wf_generate<false>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
-    const int ext_blocks = num_cus * 8;
+    const int ext_blocks = (int)(L.stack_stride / 256u); // rt_scene.cpp sizes the overflow workspace for exactly this grid
     const int shade_blocks = num_cus * 8;
     uint32_t *h_count = L.host_count; // pinned word owned by the scene: per-bounce queue size read-back
     uint32_t n_active = L.n_paths;
