@@ -149,6 +149,8 @@ def main() -> None:
     ap.add_argument("--film", default="device", choices=["device", "none"], help="device: rt_render_rgb8 (film on the GPU, rgb8 gathered); none: rt_render (float3 gathered)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 flow on fewer GPUs (all ranks on GPU 0, gather staged through host)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--bvh", default="reference", choices=["reference", "device"],
+                    help="reference: host build in the reference's exact topology (parity mode, the headline); device: LBVH built on the GPU (production mode: same closest hits, other topology)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
 
@@ -181,7 +183,7 @@ def main() -> None:
     tex_size = args.tex_size or wl["tex_size"]
     n_pix = W * H
     full_size = (W, H, n_tri, tex_size) == (wl["width"], wl["height"], wl["triangles"], wl["tex_size"]) and spp == wl["spp_per_gpu"] * world
-    workload_id = args.workload if full_size else f"{args.workload}-custom"
+    workload_id = (args.workload if full_size else f"{args.workload}-custom") + ("" if args.bvh == "reference" else "-lbvh")
 
     t0 = time.time()
     scene = rt.scenegen.room_scene(n_tri, seed=SEED, tex_size=tex_size, n_tex_sets=16, n_materials=64, n_lights=16,
@@ -189,8 +191,9 @@ def main() -> None:
                                    camera=rt.scenegen.look_camera((-15.0, 4.0, 0.0), yaw_deg=-90.0, yfov=0.9, aspect=W / H))
     t_gen = time.time() - t0
     t0 = time.time()
-    dev = rt.DeviceScene(scene, device=local_rank)
+    dev = rt.DeviceScene(scene, device=local_rank, device_bvh=args.bvh == "device")
     t_create = time.time() - t0
+    build_times = dev.build_times()
 
     block = SHARD_ROWS * W
     sharding = importlib.import_module("raytracing-course-hw-public_amd.sharding")
@@ -351,10 +354,11 @@ def main() -> None:
                 "triangles": int(scene.n_triangles),
                 "sharding": f"interleaved {SHARD_ROWS}-row tiles over {world} GPU(s), RCCL gather of the {'rgb8 image' if film else 'float3 framebuffer'}" if world > 1 else "single GPU",
                 "film": "device (rt_render_rgb8)" if film else "none (linear float3)",
+                "bvh": "reference topology, host build (parity mode)" if args.bvh == "reference" else "LBVH built on the device (production mode: identical closest hits, different topology and counters)",
             },
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
-            "setup_s": {"scene_generation": round(t_gen, 2), "rt_create_bvh_upload": round(t_create, 2)},
+            "setup_s": {"scene_generation": round(t_gen, 2), "rt_create_bvh_upload": round(t_create, 2), "scene_bvh_build": round(build_times["build_ms"] / 1e3, 4)},
         }
         print(json.dumps(out), flush=True)
     dev.close()

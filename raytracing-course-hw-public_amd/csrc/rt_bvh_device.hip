@@ -10,9 +10,9 @@
 //
 //   1. scene bounds              block reduction + ordered-integer atomics
 //   2. 30-bit Morton code of every triangle's centre (triangle::center, geometry.h:485-487), radix sort (rocPRIM)
-//   3. leaves = runs of up to 4 consecutive sorted triangles (the reference's leaves hold 3.9 on average, bvh.h:343-346);
-//      per leaf: DevTri / DevAttr records in sorted order, exact AABB of its vertices, 64-bit key = Morton of its first
-//      triangle : leaf index (unique, sorted)
+//   3. leaves = runs of LEAF consecutive sorted triangles (default 1; the reference's leaves hold 3.9 on average,
+//      bvh.h:343-346); per leaf: DevTri / DevAttr records in sorted order, exact AABB of its vertices, 64-bit key = Morton
+//      of its first triangle : leaf index (unique, sorted)
 //   4. Karras 2012 radix tree over the leaf keys: every inner node finds its own range and split independently
 //   5. bottom-up refit: each leaf walks to the root; the second thread to arrive at a node has both child boxes, writes
 //      them into that node's DevNode and carries the union upwards (one agent-scope fence + atomic per hand-off)
@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -35,7 +37,10 @@
 
 namespace {
 
-constexpr uint32_t LEAF_TRIS = 4;
+// Triangles per leaf. Measured (tools/lbvh_probe.py, profiles/r02_lbvh.txt): 1 renders fastest at both scene sizes
+// (262 k triangles: 83 ms against 107 ms on the reference's tree; 10^7: 166 against 141 ms), 2 and 4 are slower (loose leaf
+// boxes along the Morton curve), so the default is one triangle per leaf; RT_LBVH_LEAF (1..8) overrides it for experiments.
+constexpr uint32_t LEAF_TRIS_DEFAULT = 1;
 
 __device__ __forceinline__ uint32_t enc_f(float f) { // order-preserving float -> uint
     const uint32_t b = __float_as_uint(f);
@@ -116,7 +121,7 @@ struct BuildArrays {
     const float *pos, *nrm, *tan, *uv;
     const uint32_t *mat;
     const uint32_t *keys_sorted, *prims_sorted;
-    uint32_t n, n_leaves;
+    uint32_t n, n_leaves, leaf_tris;
     DevTri *tris;
     DevAttr *attrs;
     DevNode *nodes;
@@ -136,7 +141,7 @@ __device__ __forceinline__ bool coord_fast_ok(float c) {
 // ---- 3. leaves: records in sorted order, exact boxes, keys
 __global__ __launch_bounds__(256) void k_leaves(const BuildArrays A) {
     for (uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x; leaf < A.n_leaves; leaf += gridDim.x * blockDim.x) {
-        const uint32_t k0 = leaf * LEAF_TRIS, k1 = min(k0 + LEAF_TRIS, A.n);
+        const uint32_t k0 = leaf * A.leaf_tris, k1 = min(k0 + A.leaf_tris, A.n);
         float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
         bool ok = true;
         for (uint32_t k = k0; k < k1; ++k) {
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void k_leaves(const BuildArrays A) {
 }
 
 __device__ __forceinline__ uint32_t leaf_ref(const BuildArrays &A, uint32_t leaf) {
-    const uint32_t k0 = leaf * LEAF_TRIS, cnt = min(LEAF_TRIS, A.n - k0);
+    const uint32_t k0 = leaf * A.leaf_tris, cnt = min(A.leaf_tris, A.n - k0);
     return RT_LEAF_FLAG | (cnt << 27) | k0;
 }
 
@@ -271,8 +276,8 @@ __global__ __launch_bounds__(256) void k_refit(const BuildArrays A) {
             __threadfence();
             DevNode &nd = A.nodes[node];
             const uint32_t lref = nd.left, rref = nd.right;
-            const float *lb = (lref & RT_LEAF_FLAG) ? A.leaf_box + 6ull * ((lref & RT_LEAF_BEGIN_MASK) / LEAF_TRIS) : A.node_box + 6ull * lref;
-            const float *rb = (rref & RT_LEAF_FLAG) ? A.leaf_box + 6ull * ((rref & RT_LEAF_BEGIN_MASK) / LEAF_TRIS) : A.node_box + 6ull * rref;
+            const float *lb = (lref & RT_LEAF_FLAG) ? A.leaf_box + 6ull * ((lref & RT_LEAF_BEGIN_MASK) / A.leaf_tris) : A.node_box + 6ull * lref;
+            const float *rb = (rref & RT_LEAF_FLAG) ? A.leaf_box + 6ull * ((rref & RT_LEAF_BEGIN_MASK) / A.leaf_tris) : A.node_box + 6ull * rref;
             float l6[6], r6[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
@@ -336,7 +341,10 @@ hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBv
     Tmp tmp;
     float *pos, *nrm, *tan, *uv;
     uint32_t *mat, *keys[2], *vals[2], *bounds, *leaf_parent, *node_parent, *arrived, *fast_bad;
-    const uint32_t n_leaves = (n + LEAF_TRIS - 1) / LEAF_TRIS;
+    uint32_t leaf_tris = LEAF_TRIS_DEFAULT;
+    if (const char *e = std::getenv("RT_LBVH_LEAF"))
+        leaf_tris = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
+    const uint32_t n_leaves = (n + leaf_tris - 1) / leaf_tris;
     BUILD_TRY(tmp.alloc(&pos, 9ull * n));
     BUILD_TRY(tmp.alloc(&nrm, 9ull * n));
     BUILD_TRY(tmp.alloc(&tan, 9ull * n));
@@ -387,7 +395,7 @@ hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBv
     BuildArrays A{};
     A.pos = pos, A.nrm = nrm, A.tan = tan, A.uv = uv, A.mat = mat;
     A.keys_sorted = keys[1], A.prims_sorted = vals[1];
-    A.n = n, A.n_leaves = n_leaves;
+    A.n = n, A.n_leaves = n_leaves, A.leaf_tris = leaf_tris;
     BUILD_TRY(out_alloc((void **)&A.tris, sizeof(DevTri) * (size_t)n));
     BUILD_TRY(out_alloc((void **)&A.attrs, sizeof(DevAttr) * (size_t)n));
     BUILD_TRY(out_alloc((void **)&A.nodes, sizeof(DevNode) * (size_t)(n_leaves > 1 ? n_leaves - 1 : 1)));

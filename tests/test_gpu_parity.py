@@ -452,6 +452,7 @@ def test_reference_rng_mode_close_to_reference_binary_golden(gpu, sg, oracle, tm
         img = gpu.tonemap(fb)
         ref = oracle.read_ppm(os.path.join(gold_dir, f"{name}_64x48x4.ppm"))
         differing = int((img != ref).any(axis=2).sum())
+        # observed (tools/closeness_probe.py): room_plain 22 of 3072 pixels (0.7 %), boxes 0
         assert differing <= 0.02 * 64 * 48, f"{name}: {differing} of {64 * 48} pixels differ from the reference binary's PPM"
         dev.close()
 
@@ -476,7 +477,8 @@ def test_feature_gltf_through_loader_matches_oracle_and_reference(gpu, oracle):
     ref = oracle.read_ppm(os.path.join(gold, "features_64x48x4.ppm"))
     differing = int((img != ref).any(axis=2).sum())
     mean_abs = float(np.abs(img.astype(np.int32) - ref.astype(np.int32)).mean())
-    assert differing <= 0.15 * 64 * 48 and mean_abs < 4.0, f"{differing} of {64 * 48} pixels differ from the reference binary's PPM, mean |d| {mean_abs}"
+    # observed (tools/closeness_probe.py): 170 of 3072 pixels (5.5 %), mean |d| 2.23; bound = observed + ~50 % margin
+    assert differing <= 0.085 * 64 * 48 and mean_abs < 3.3, f"{differing} of {64 * 48} pixels differ from the reference binary's PPM, mean |d| {mean_abs}"
     dev.close()
     orc.close()
 
