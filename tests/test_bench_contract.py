@@ -27,7 +27,38 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # the line must say what `achieved` is, where `traffic` comes from (or why it is null), and carry the PMC-derived keys
+    for k in ("achieved_is", "traffic_source", "hbm_rate", "hbm_frac", "request_rate_Greq_s", "request_roof_Greq_s", "request_frac", "limiter", "pmc",
+              "peak_measured_read", "peak_measured_source", "kernel", "kernel_src_sha16", "launches_per_step", "avg_launch_ms", "algorithmic_bytes_per_launch", "pipeline"):
+        assert k in rf, k
+    assert "ALGORITHMIC" in rf["achieved_is"] and len(rf["kernel_src_sha16"]) == 16
+    # a custom (tiny) configuration has no committed profile: traffic is null and the reason is given, never a stale number
+    assert j["config"]["workload_id"] == "sponza-custom" and rf["traffic"] is None and rf["hbm_frac"] is None and "absent" in rf["traffic_source"]
+    assert rf["pmc"]["source"] is None and "absent" in rf["pmc"]["note"]
+    assert rf["peak_measured_read"] and rf["peak_measured_source"].startswith("profiles/")
+    for k in ("casts_per_sample", "nodes_per_cast", "tri_tests_per_cast", "algorithmic_bytes_per_sample"):
+        assert rf["pipeline"][k] > 0
     cb = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_committed_profiles_match_the_shipped_kernels():
+    """The PMC summaries bench.py quotes on the full-size workloads are stamped with the hash of the device sources they were
+    measured on: if the kernels changed after the last profiling pass this fails (re-run tools/final_profile.sh), so a
+    stale traffic figure can never reach a bench line unnoticed. CPU-only check."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    sha = bench.kernel_source_hash()
+    for wl in ("sponza", "s10m"):
+        for name in ("hbm_traffic", "pmc_wf_extend"):
+            j, why = bench.load_profile(name, wl, sha)
+            assert j is not None, why
+            assert j["kernel_src_sha16"] == sha
+        t, _ = bench.load_profile("hbm_traffic", wl, sha)
+        assert t["hbm_bytes_per_launch"] > 0 and t["read_requests_per_launch"] > 0 and t["request_roof_Greq_s"] > 0
+        p, _ = bench.load_profile("pmc_wf_extend", wl, sha)
+        for k in ("valu_busy", "lanes_per_valu", "wait_any_frac", "l2_hit", "limiter"):
+            assert p[k], k
