@@ -48,8 +48,14 @@ int rt_film_table(float thr[256], uint32_t special[3]);
 int rt_bvh_build_host(const float *positions, uint32_t n_triangles, const uint32_t *subset, uint32_t n_subset, uint32_t *n_nodes, uint32_t *root,
                       uint32_t *nodes_out, uint32_t *order_out);
 
-/* PNG (8-bit, non-interlaced) -> RGBA8, the subset of stb_image the fixtures need. Caller frees with rt_free. */
+/* Texture::load_img (geometry.h:584-598: stbi_load with 4 channels forced) for the formats this loader reads, told apart by
+ * their signatures: PNG (every colour type / bit depth / Adam7 / tRNS) and JPEG (baseline, extended-sequential and progressive
+ * Huffman, 8 bit, 1 or 3 components, any sampling factors that divide the maximum, restart intervals). Both return the bytes
+ * stb_image v2.30 returns (pinned by fixtures decoded with the reference's own stb build). Other formats stb_image reads
+ * (BMP, TGA, GIF, PSD, HDR, PNM) are refused with RT_ERR_FORMAT and a message that names the format. Caller frees with rt_free. */
+int rt_image_decode_file(const char *path, uint32_t *w, uint32_t *h, uint8_t **rgba8);
 int rt_png_decode_file(const char *path, uint32_t *w, uint32_t *h, uint8_t **rgba8);
+int rt_jpeg_decode_file(const char *path, uint32_t *w, uint32_t *h, uint8_t **rgba8);
 void rt_free(void *p);
 
 #ifdef __cplusplus

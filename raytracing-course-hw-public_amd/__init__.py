@@ -303,6 +303,17 @@ def write_ppm(path: str, rgb8: np.ndarray) -> None:
     _check(lib().rt_write_ppm(os.fsencode(path), w, h, u8ptr(rgb8)))
 
 
+def image_decode(path: str) -> np.ndarray:
+    """Texture::load_img (geometry.h:584-598) for PNG and JPEG files: (H, W, 4) uint8, the bytes stb_image returns."""
+    w, h = C.c_uint32(), C.c_uint32()
+    p = c_u8_p()
+    _check(lib().rt_image_decode_file(os.fsencode(path), C.byref(w), C.byref(h), C.byref(p)))
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib().rt_free(p)
+
+
 def png_decode(path: str) -> np.ndarray:
     w, h = C.c_uint32(), C.c_uint32()
     p = c_u8_p()

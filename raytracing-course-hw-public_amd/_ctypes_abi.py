@@ -166,6 +166,8 @@ HOST_PROTOTYPES = {
     "rt_loaded_free": (None, [C.c_void_p]),
     "rt_write_ppm": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, c_u8_p]),
     "rt_png_decode_file": (C.c_int, [C.c_char_p, c_u32_p, c_u32_p, C.POINTER(c_u8_p)]),
+    "rt_jpeg_decode_file": (C.c_int, [C.c_char_p, c_u32_p, c_u32_p, C.POINTER(c_u8_p)]),
+    "rt_image_decode_file": (C.c_int, [C.c_char_p, c_u32_p, c_u32_p, C.POINTER(c_u8_p)]),
     "rt_free": (None, [C.c_void_p]),
     "rt_film_table": (C.c_int, [c_float_p, c_u32_p]),
     "rt_bvh_build_host": (C.c_int, [c_float_p, C.c_uint32, c_u32_p, C.c_uint32, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),

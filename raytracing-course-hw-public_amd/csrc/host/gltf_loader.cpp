@@ -142,7 +142,7 @@ void load_impl(const std::filesystem::path &gltf_path, float ar, rt_loaded_scene
         uint32_t w = 0, h = 0;
         uint8_t *px = nullptr;
         std::string path = (gltf_path.parent_path() / uri).string();
-        if (rt_png_decode_file(path.c_str(), &w, &h, &px) != RT_OK)
+        if (rt_image_decode_file(path.c_str(), &w, &h, &px) != RT_OK)
             throw std::runtime_error(rt::last_error());
         res.texels.push_back(px);
         res.textures.push_back({w, h, px});

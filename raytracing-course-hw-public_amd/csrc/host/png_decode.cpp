@@ -11,8 +11,9 @@
 //   * 4 output channels always: grey -> g,g,g,a and RGB -> r,g,b,a with a = 255 unless the file says otherwise;
 //   * chunk CRCs are not verified (stb_image skips them); an unknown CRITICAL chunk is an error, ancillary ones are skipped;
 //   * dimensions above 2^24 (STBI_MAX_DIMENSIONS) or 2^28 pixels are refused before anything is allocated.
-// Not PNG: JPEG / BMP / TGA / GIF / PSD / HDR / PNM, which stb_image would also read, are NOT supported by this loader:
-// the error message names the format so that a user knows to convert the texture (DESIGN.md "loader differences").
+// JPEG is read by jpeg_decode.cpp (rt_image_decode_file picks the decoder by signature). BMP / TGA / GIF / PSD / HDR / PNM,
+// which stb_image would also read, are NOT supported: the error message names the format so that a user knows to convert
+// the texture (INTEGRATION.md "Loader differences").
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -120,7 +121,7 @@ extern "C" int rt_png_decode_file(const char *path, uint32_t *w_out, uint32_t *h
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) {
         if (const char *other = sniff_other_format(file))
-            return rt::fail(RT_ERR_FORMAT, std::string(path) + ": " + other + " image: only PNG textures are supported by this loader (stb_image, which the reference uses, would read it; convert the texture to PNG)");
+            return rt::fail(RT_ERR_FORMAT, std::string(path) + ": " + other + " image: this loader reads PNG and JPEG textures only (stb_image, which the reference uses, would read it; convert the texture)");
         return rt::fail(RT_ERR_FORMAT, std::string("not a PNG file: ") + path);
     }
     uint32_t w = 0, h = 0;

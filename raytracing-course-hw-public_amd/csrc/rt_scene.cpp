@@ -697,7 +697,7 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
             s->wf_host_count = nullptr;
         W.host_count = s->wf_host_count;
         W.sort_temp = s->wf_sort_temp;
-        W.sort_mode = sort_env ? (uint32_t)std::atoi(sort_env) : 1u;
+        W.sort_mode = sort_env ? (uint32_t)std::atoi(sort_env) : 4u; // 24-bit key: cell, octant, direction sub-cone (measured best)
         W.sort_temp_bytes = s->wf_sort_temp_bytes;
         W.stats = L.stats;
         for (uint64_t p0 = 0; p0 < local_pixels; p0 += tile_pixels) {

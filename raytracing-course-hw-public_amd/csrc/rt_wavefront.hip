@@ -467,6 +467,10 @@ __global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLa
             key = (m16 << 9) | (dxq << 6) | (dyq << 3) | dzq;
         } else if (L.sort_mode == 3) { // octant first, then the 64^3 cell
             key = (oct << 18) | morton;
+        } else if (L.sort_mode == 4) { // 64^3 cell, octant, then which of the octant's 8 sub-cones the direction lies in (24 bits)
+            const float ax = __builtin_fabsf(r0.w), ay = __builtin_fabsf(r1.x), az = __builtin_fabsf(r1.y);
+            const uint32_t sub = (ax > ay ? 1u : 0u) | (ay > az ? 2u : 0u) | (ax > az ? 4u : 0u);
+            key = (((morton << 3) | oct) << 3) | sub;
         }
         L.sort_keys[0][j] = key;
         L.sort_vals[0][j] = j;
@@ -551,7 +555,7 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
                 const uint32_t kb = (n_active + 255u) / 256u < (uint32_t)num_cus * 16u ? (n_active + 255u) / 256u : (uint32_t)num_cus * 16u;
                 WF_LAUNCH(wf_sort_keys, dim3(kb), block, 0, stream, S, L, n_active);
                 size_t tmp = L.sort_temp_bytes;
-                hipError_t se = rocprim::radix_sort_pairs(L.sort_temp, tmp, L.sort_keys[0], L.sort_keys[1], L.sort_vals[0], L.sort_vals[1], (size_t)n_active, 0u, 21u, stream);
+                hipError_t se = rocprim::radix_sort_pairs(L.sort_temp, tmp, L.sort_keys[0], L.sort_keys[1], L.sort_vals[0], L.sort_vals[1], (size_t)n_active, 0u, L.sort_mode == 4 ? 24u : 21u, stream);
                 if (se != hipSuccess)
                     return se;
                 L.order = L.sort_vals[1];
@@ -588,7 +592,7 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
 size_t wavefront_sort_temp_bytes(size_t n) {
     size_t tmp = 0;
     uint32_t *k = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp, k, k, k, k, n, 0u, 21u, (hipStream_t) nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, k, k, k, k, n, 0u, 24u, (hipStream_t) nullptr);
     return tmp;
 }
 

@@ -44,21 +44,29 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
 
 
-def test_committed_profiles_match_the_shipped_kernels():
-    """The PMC summaries bench.py quotes on the full-size workloads are stamped with the hash of the device sources they were
-    measured on: if the kernels changed after the last profiling pass this fails (re-run tools/final_profile.sh), so a
-    stale traffic figure can never reach a bench line unnoticed. CPU-only check."""
+def test_committed_profiles_are_stamped_and_stale_ones_are_never_quoted():
+    """The PMC summaries bench.py quotes on the full-size workloads carry the hash of the device sources they were measured
+    on. Either they describe the kernels that are shipped (then every figure the bench line copies must be there), or the
+    kernels changed after the last profiling pass — then bench.load_profile must refuse them with a reason, so a stale
+    traffic figure can never reach a bench line. RT_STRICT_PROFILES=1 (set by the round's final profiling workflow) turns
+    staleness itself into a failure. CPU-only check."""
     sys.path.insert(0, ROOT)
     import bench
 
     sha = bench.kernel_source_hash()
+    strict = os.environ.get("RT_STRICT_PROFILES") == "1"
     for wl in ("sponza", "s10m"):
         for name in ("hbm_traffic", "pmc_wf_extend"):
+            raw = json.load(open(os.path.join(ROOT, "profiles", f"{bench.PROFILE_ROUND}_{name}_{wl}.json")))
+            assert len(raw.get("kernel_src_sha16", "")) == 16, (wl, name)
             j, why = bench.load_profile(name, wl, sha)
+            if raw["kernel_src_sha16"] != sha:
+                assert j is None and "stale" in why, (wl, name)
+                assert not strict, f"profiles/{bench.PROFILE_ROUND}_{name}_{wl}.json is stale: re-run tools/final_profile.sh"
+                continue
             assert j is not None, why
-            assert j["kernel_src_sha16"] == sha
-        t, _ = bench.load_profile("hbm_traffic", wl, sha)
-        assert t["hbm_bytes_per_launch"] > 0 and t["read_requests_per_launch"] > 0 and t["request_roof_Greq_s"] > 0
-        p, _ = bench.load_profile("pmc_wf_extend", wl, sha)
-        for k in ("valu_busy", "lanes_per_valu", "wait_any_frac", "l2_hit", "limiter"):
-            assert p[k], k
+            if name == "hbm_traffic":
+                assert j["hbm_bytes_per_launch"] > 0 and j["read_requests_per_launch"] > 0 and j["request_roof_Greq_s"] > 0
+            else:
+                for k in ("valu_busy", "lanes_per_valu", "wait_any_frac", "l2_hit", "limiter"):
+                    assert j[k], k

@@ -27,7 +27,8 @@ def test_fixture_set_covers_the_format():
 
 
 def test_other_formats_are_named_in_the_error(rt, tmp_path):
-    """stb_image would also read JPEG / BMP / ...; this loader does not, and says which format it met."""
+    """stb_image would also read BMP / GIF / ...; this loader does not, and says which format it met (JPEG goes to the JPEG
+    decoder through rt_image_decode_file; the PNG entry point alone names it too)."""
     for blob, word in ((b"\xff\xd8\xff\xe0" + b"\x00" * 32, "JPEG"), (b"BM" + b"\x00" * 32, "BMP"), (b"GIF89a" + b"\x00" * 32, "GIF")):
         p = tmp_path / "x.bin"
         p.write_bytes(blob)

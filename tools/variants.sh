@@ -9,7 +9,7 @@ for spec in "$@"; do
   /opt/rocm/bin/hipcc -std=c++20 -O3 -ffp-contract=off -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 -fno-slp-vectorize $flags -c rt_kernels.hip -o variants/$name.k.o &
   /opt/rocm/bin/hipcc -std=c++20 -O3 -ffp-contract=off -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 -fno-slp-vectorize $flags -c rt_wavefront.hip -o variants/$name.w.o &
   wait
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/$name.so host/film.o host/png_decode.o host/gltf_loader.o host/txt_loader.o bvh_build.o rt_scene.o rt_group.o rt_film.o rt_bvh_device.o variants/$name.k.o variants/$name.w.o -lz -ldl
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/$name.so host/film.o host/png_decode.o host/jpeg_decode.o host/gltf_loader.o host/txt_loader.o bvh_build.o rt_scene.o rt_group.o rt_film.o rt_bvh_device.o variants/$name.k.o variants/$name.w.o -lz -ldl
   rm -f variants/$name.k.o variants/$name.w.o
   echo "built $name ($flags)"
 done
