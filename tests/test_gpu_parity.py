@@ -556,3 +556,35 @@ def test_render_rgb8_device_destination(pairs, gpu, oracle):
     torch.cuda.synchronize()
     ofb, _ = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=2)
     assert np.array_equal(t.cpu().numpy().reshape(H, W, 3), oracle.tonemap(ofb))
+
+
+def test_config4_shape_1000_spp_on_the_bench_scene(gpu, oracle, sg):
+    """BASELINE config 4 on one GPU: S-sponza 1000x1000 at 1000 SPP = 10^9 samples, rendered in 16 sample passes of 64 M
+    paths whose partial sums must continue in sample order (raytracer.h:621-626). Two 256-pixel spans of the image are
+    recomputed by the oracle at the full 1000 SPP (bit-exact), and the union of the 8 interleaved shards the 8 ranks of that
+    configuration would render equals the single render (same blocks, same bytes the RCCL gather would move)."""
+    W = H = 1000
+    SPP = 1000
+    sc = sg.room_scene(262144, seed=0x5EED5EED, tex_size=256, n_tex_sets=16, n_materials=64, n_lights=16, light_strength=20.0,
+                       alpha_fraction=0.02, offset=0.15, camera=sg.look_camera((-15.0, 4.0, 0.0), yaw_deg=-90.0, yfov=0.9))
+    dev = gpu.DeviceScene(sc)
+    orc = oracle.OracleScene(sc)
+    try:
+        img, st = dev.run_raytracer_rgb8(W, H, SPP, seed=0xC4)
+        assert st["samples"] == W * H * SPP and st["dominant_launches"] >= 16 * 8 - 8  # 16 passes x (up to) 8 bounces
+        fb, _ = dev.run_raytracer(W, H, SPP, seed=0xC4)
+        assert np.array_equal(img, gpu.tonemap(fb))
+        n_spans = (W * H + 255) // 256
+        for span in (1234, 3000):
+            ofb = np.full((H, W, 3), -1.0, dtype=np.float32)
+            orc.run_raytracer(W, H, SPP, seed=0xC4, shard_index=span, shard_count=n_spans, shard_block=256, out=ofb)
+            mine = (ofb.reshape(-1, 3)[:, 0] != -1.0)
+            assert int(mine.sum()) == 256
+            assert np.array_equal(fb.reshape(-1, 3)[mine].view(np.uint32), ofb.reshape(-1, 3)[mine].view(np.uint32)), span
+        acc = np.zeros_like(img)
+        for r in range(8):
+            dev.run_raytracer_rgb8(W, H, SPP, seed=0xC4, shard_index=r, shard_count=8, shard_block=8 * W, out=acc)
+        assert np.array_equal(acc, img)
+    finally:
+        dev.close()
+        orc.close()
