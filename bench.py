@@ -35,8 +35,12 @@ The "roofline" object (dominant kernel wf_extend):
                        requests per launch / live launch duration / the ~55 G requests/s this chip sustains for random
                        gathers of <= 64-B records (tools/ubench/gather64.hip, profiles/r02_gather64_calibration.txt): the
                        practical roof of this kernel's access pattern, which is request-rate bound, not byte bound.
-  limiter + pmc        what the SQ/TCP/TCC counters of the same committed profile say binds the kernel (VALU issue share,
-                       active lanes per VALU instruction, wave-wait share, L2 hit rate), each with its source file.
+  l1_frac              vector-L1 (TCP) tag accesses per clock per CU of wf_extend (same committed PMC profile) / the 0.98 the
+                       chip retires at most (tools/l1_roof_probe.sh, profiles/r02_l1_roof.txt). A 64-byte node costs four
+                       16-byte loads = four L1 accesses per lane whatever its cache residency: this is the roof that binds
+                       the kernel on both workloads (S-sponza 0.8 of it at HBM 0.2; S-10M 0.7 with 42 % miss stalls).
+  limiter + pmc        what the SQ/TCP/TCC counters of the same committed profile say binds the kernel (L1 access rate,
+                       VALU issue share, active lanes per VALU instruction, wave-wait share, hit rates), with its source file.
 "cpu_baseline": the CPU oracle (port of the reference algorithm, byte-identical to the reference binary on the
 fixtures) timed on this box's host cores on a bounded sample of the same workload; rank 0, N = 1 only.
 """
@@ -265,7 +269,8 @@ def main() -> None:
                               "sources (hash checked); FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md; not measured in this run")
         pj, pmc_source = load_profile("pmc_wf_extend", workload_id, src_hash)
         if pj is not None:
-            pmc = {k: pj.get(k) for k in ("valu_busy", "lanes_per_valu", "wait_any_frac", "l1_hit", "l2_hit", "salu_per_valu", "workload", "spp")}
+            pmc = {k: pj.get(k) for k in ("valu_busy", "lanes_per_valu", "wait_any_frac", "l1_hit", "l2_hit", "salu_per_valu", "l1_accesses_per_clk_per_cu",
+                                          "l1_roof_accesses_per_clk_per_cu", "l1_frac", "l1_miss_rate_Greq_s", "l1_pending_stall_frac", "shader_clock_ghz", "workload", "spp")}
             pmc["source"] = pj["_file"] + " (earlier rocprofv3 --pmc run, same device sources)"
             limiter = pj.get("limiter")
         else:
@@ -285,6 +290,7 @@ def main() -> None:
         "request_rate_Greq_s": round(requests / avg_launch_s / 1e9, 2) if requests else None,
         "request_roof_Greq_s": request_roof,
         "request_frac": round(requests / avg_launch_s / 1e9 / request_roof, 4) if requests and request_roof else None,
+        "l1_frac": pmc.get("l1_frac") if pmc else None,  # vector-L1 tag accesses per clock per CU / the measured 0.98 roof (profiles/r02_l1_roof.txt)
         "limiter": limiter,
         "pmc": pmc,
         "peak_measured_read": stream_peak,

@@ -129,6 +129,28 @@ DEV void diag_add(int slot, unsigned long long v) {
 #define DIAG_LANES(slot) do { } while (0)
 #endif
 
+// Development-only section census of wf_shade (-DRT_DIAG_SHADE): wave cycles (s_memtime) and active lanes between stamps,
+// accumulated per wave in LDS and flushed to the census words at kernel end. Never compiled into the product.
+#ifdef RT_DIAG_SHADE
+enum { SD_LOAD = 0, SD_ATTR, SD_TEX, SD_SAMPLE, SD_PDF_LIGHTS, SD_BRDF, SD_FOLD, SD_STORE, SD_N };
+__shared__ unsigned long long g_sd_cyc[4][SD_N], g_sd_lanes[4][SD_N], g_sd_cnt[4][SD_N], g_sd_t[4];
+DEV void sd_stamp(int section) { // attribute the cycles since the previous stamp of this wave to `section`
+    const unsigned long long m = __ballot(1);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    if (rank == 0) {
+        const uint32_t w = threadIdx.x >> 6;
+        g_sd_cyc[w][section] += now - g_sd_t[w];
+        g_sd_lanes[w][section] += (unsigned long long)__popcll(m);
+        g_sd_cnt[w][section] += 1ull;
+        g_sd_t[w] = now;
+    }
+}
+#define SD_STAMP(section) sd_stamp(section)
+#else
+#define SD_STAMP(section) do { } while (0)
+#endif
+
 
 // ---------------------------------------------------------------------------------------------- RNG policy
 template <int MODE> struct Rng;
@@ -833,6 +855,7 @@ DEV Surf make_surf(const DevScene &S, const Hit &h, V3 ro, V3 rd, const float *s
         for (int i = 0; i < 4; ++i)
             q[i] = p[i];
     }
+    SD_STAMP(SD_ATTR);
     const float b = h.b, c = h.c;
     const float w0 = (1 - b - c); // triangle::interop geometry.h:497-502
     V3 normal = ld3(at.gn);
@@ -851,6 +874,7 @@ DEV Surf make_surf(const DevScene &S, const Hit &h, V3 ro, V3 rd, const float *s
     C4 ct = tex_sample(S, m.color_tex, TEX_DEFAULT_WHITE, tu, tv, true, s_lin, s_gam, st); // :615-617
     C4 et = tex_sample(S, m.emissive_tex, TEX_DEFAULT_WHITE, tu, tv, true, s_lin, s_gam, st); // :619-621
     st.shaded();
+    SD_STAMP(SD_TEX);
     Surf s;
     s.normal = is_inside ? -normal : normal;
     s.shading_normal = is_inside ? -shading : shading;
@@ -1012,6 +1036,7 @@ DEV ShadeResult shade_hit(const DevScene &S, const Hit &h, V3 ro, V3 rd, R &rng,
         out.term = ii.emission;
         return out;
     }
+    SD_STAMP(SD_SAMPLE);
     const float VNDF_p = vndf_pdf(vr, rd, ii.shading_normal, dir);
     float MIS_p;
     const float cos_p = rmax(dot(ii.normal, dir) / PI_F, 0.0f); // cosine_dist::pdf :123-128
@@ -1022,6 +1047,7 @@ DEV ShadeResult shade_hit(const DevScene &S, const Hit &h, V3 ro, V3 rd, R &rng,
         r += cos_p;
         r += lights_pdf<STATS>(S, pos, dir, stk, st);
         MIS_p = r / 2.0f;
+        SD_STAMP(SD_PDF_LIGHTS);
     }
     const float p = VNDF_FACTOR * VNDF_p + (1 - VNDF_FACTOR) * MIS_p;
     if (p < EPS) { // :576-578

@@ -144,7 +144,24 @@ struct alignas(16) WfFold { // 32 B: one pending shade() frame, `emission + inne
     float e[3], pad0;
     float s[3], pad1;
 };
-enum { WF_CNT_IN = 0, WF_CNT_OUT = 1, WF_CNT_TICKET = 2, WF_CNT_WORDS = 16 };
+enum { WF_CNT_IN = 0, WF_CNT_TICKET = 2, WF_CNT_SLOTS = 3, WF_CNT_WORDS = 16 };
+// wf_shade appends a bounce's survivors to WF_STRIPES sub-queues instead of one: a returning atomic on ONE address completes
+// every ~13 ns chip-wide, and one per wave (64 rays) of a 30 M-ray bounce made that single counter the whole kernel's clock
+// (6.3 ms of 6.3 ms; profiles/r02_shade_atomic.txt). Wave slot w of the input queue (positions 64w..64w+63) appends to
+// sub-queue w % WF_STRIPES, whose region of paths_out is sized for all of its slots (nothing can overflow) and whose counter
+// has a cache line to itself. The regions' fill levels become a dense prefix (run_start) in wf_advance; the next bounce's
+// ray-order pass (wf_sort_keys) maps dense index -> physical slot, and wf_extend / wf_shade reach rays through `order` anyway.
+#define WF_STRIPES 64u
+#define WF_STRIPE_WORDS 32u /* one counter per 128-byte line */
+#define WF_STRIPE_BUF_WORDS (WF_STRIPES * WF_STRIPE_WORDS + WF_STRIPES + 1u) /* counters, then run_start[WF_STRIPES + 1] */
+// first slot of sub-queue k when the producing launch had n_slots wave slots: slots are dealt round-robin
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline uint32_t wf_stripe_base(uint32_t k, uint32_t n_slots) {
+    const uint32_t q = n_slots / WF_STRIPES, r = n_slots % WF_STRIPES;
+    return 64u * (k * q + (k < r ? k : r));
+}
 
 struct WfLaunch {
     uint32_t width, height, samples; // image, total SPP
@@ -166,7 +183,9 @@ struct WfLaunch {
     float *fb;               // width*height*3
     void *stack_overflow;    // wf_extend's evicted traversal-stack frames: [RT_MAX_STACK][stack_stride] records of 16 B
     uint32_t stack_stride;   // = threads of the wf_extend grid
-    uint32_t *counters;      // WF_CNT_*
+    uint32_t *counters;      // WF_CNT_*: IN = rays of this bounce, TICKET = wf_extend's work ticket, SLOTS = wave slots of the launch
+                             // that wrote paths_in (0: paths_in is dense, as wf_generate leaves it)
+    uint32_t *stripes;       // WF_STRIPE_BUF_WORDS: the sub-queue fill counters of the running wf_shade, then run_start[] of paths_in
     void *diag;              // development census (-DRT_DIAG), 32 x u64, else unused
     const uint32_t *order;   // optional: position q processes queue slot order[q] (coherence sort; extend AND shade); null = identity
     uint32_t *sort_keys[2];  // sort workspace: keys / slot indices, double buffered

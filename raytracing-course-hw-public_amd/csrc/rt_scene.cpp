@@ -134,6 +134,7 @@ struct rt_scene {
     uint32_t wf_depth_cap = 0;
     std::vector<void *> wf_owned;
     WfPath *wf_paths[2] = {nullptr, nullptr};
+    uint32_t *wf_stripes = nullptr;
     WfHit *wf_hits = nullptr;
     WfFold *wf_fold = nullptr;
     RtF4 *wf_samples = nullptr, *wf_accum = nullptr;
@@ -162,7 +163,9 @@ struct rt_scene {
             return RT_OK;
         };
         int rc;
-        if ((rc = alloc(paths * sizeof(WfPath), (void **)&wf_paths[0])) != RT_OK || (rc = alloc(paths * sizeof(WfPath), (void **)&wf_paths[1])) != RT_OK ||
+        // + 64: wf_shade's sub-queue regions cover whole wave slots (rt_device_types.h, WF_STRIPES)
+        if ((rc = alloc((paths + 64) * sizeof(WfPath), (void **)&wf_paths[0])) != RT_OK || (rc = alloc((paths + 64) * sizeof(WfPath), (void **)&wf_paths[1])) != RT_OK ||
+            (rc = alloc(WF_STRIPE_BUF_WORDS * sizeof(uint32_t), (void **)&wf_stripes)) != RT_OK ||
             (rc = alloc(paths * sizeof(WfHit), (void **)&wf_hits)) != RT_OK || (rc = alloc(paths * depth * sizeof(WfFold), (void **)&wf_fold)) != RT_OK ||
             (rc = alloc(paths * sizeof(RtF4), (void **)&wf_samples)) != RT_OK || (rc = alloc(pixels * sizeof(RtF4), (void **)&wf_accum)) != RT_OK ||
             (rc = alloc(WF_CNT_WORDS * sizeof(uint32_t) + 1024, (void **)&wf_counters)) != RT_OK)
@@ -705,14 +708,14 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
         W.accum = s->wf_accum;
         W.fb = d_fb;
         W.counters = s->wf_counters;
+        W.stripes = s->wf_stripes;
         W.stack_overflow = s->wf_stack_overflow;
         W.stack_stride = s->wf_stack_stride;
         W.diag = s->wf_counters + 64; // dev census words live behind the queue counters
         const char *sort_env = std::getenv("RT_WF_SORT");
-        const bool sort_rays = sort_env ? std::atoi(sort_env) != 0 : true;
-        for (int k = 0; k < 2; ++k) {
-            W.sort_keys[k] = sort_rays ? s->wf_sort_keys[k] : nullptr;
-            W.sort_vals[k] = sort_rays ? s->wf_sort_vals[k] : nullptr;
+        for (int k = 0; k < 2; ++k) { // sort_vals[1] also carries the unsorted order (RT_WF_SORT=0: sort_mode 0)
+            W.sort_keys[k] = s->wf_sort_keys[k];
+            W.sort_vals[k] = s->wf_sort_vals[k];
         }
         if (!s->wf_host_count && hipHostMalloc((void **)&s->wf_host_count, sizeof(uint32_t)) != hipSuccess)
             s->wf_host_count = nullptr;

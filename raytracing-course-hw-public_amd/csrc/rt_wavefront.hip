@@ -42,6 +42,9 @@ using ExtStack = RingStackT<RT_EXT_LDS_DEPTH>;
 #ifndef RT_SHADE_WAVES_PER_SIMD
 #define RT_SHADE_WAVES_PER_SIMD 4
 #endif
+#ifndef RT_SHADE_BLOCKS_PER_CU
+#define RT_SHADE_BLOCKS_PER_CU 8 /* grid of the grid-stride kernels (wf_shade, wf_extend_prims) */
+#endif
 #ifndef RT_SHADE_LDS_DEPTH
 #define RT_SHADE_LDS_DEPTH 4 /* only the light-BVH traversal of bvh_mix_dist::pdf uses a stack in wf_shade */
 #endif
@@ -353,11 +356,18 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
     __shared__ uint32_t s_stack[STACK_LDS_DWORDS_FOR(RT_SHADE_LDS_DEPTH)];
     s_lin[threadIdx.x] = S.lut_linear[threadIdx.x];
     s_gam[threadIdx.x] = S.lut_gamma[threadIdx.x];
+#ifdef RT_DIAG_SHADE
+    if (threadIdx.x < 4u * SD_N)
+        (&g_sd_cyc[0][0])[threadIdx.x] = 0ull, (&g_sd_lanes[0][0])[threadIdx.x] = 0ull, (&g_sd_cnt[0][0])[threadIdx.x] = 0ull;
+    if ((threadIdx.x & 63u) == 0u)
+        g_sd_t[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
     LaneStats<STATS> st;
     RT_DECLARE_STACK(stk, RT_SHADE_LDS_DEPTH, s_stack);
     const bool has_lights = S.lights.n_tris != 0; // raytracer.h:449-453
     const uint32_t n_in = L.counters[WF_CNT_IN];
+    const uint32_t n_slots = (n_in + 63u) >> 6; // wave slots of this launch: positions 64w .. 64w+63
     const uint32_t stride = gridDim.x * blockDim.x;
     // wave-uniform trip count: ballots below must see the whole wave
     for (uint32_t base = blockIdx.x * blockDim.x; base < n_in; base += stride) {
@@ -380,7 +390,9 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
             h.k = __float_as_uint(hq.x), h.b = hq.y, h.c = hq.z, h.t = hq.w;
             if (h.k != RT_NONE)
                 depth_left -= 1; // shade(..., max_depth - 1)
+            SD_STAMP(SD_LOAD);
             const ShadeResult sr = shade_hit<Rng<RT_RNG_DEVICE>, STATS>(S, h, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), rng, has_lights, stk, s_lin, s_gam, st);
+            SD_STAMP(SD_BRDF);
             bool terminal = sr.terminal;
             V3 term = sr.term;
             if (sr.push) { // emission + trace_ray(...) * scl (raytracer.h:588-590), folded when the path ends
@@ -410,6 +422,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
                     res.z = 0;
                 L.sample_out[path] = RtF4{res.x, res.y, res.z, 0.f};
                 st.sample();
+                SD_STAMP(SD_FOLD);
             } else {
                 survive = true;
                 st.cast();
@@ -419,14 +432,16 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
                 nrng = make_uint4(rng.g.s[0], rng.g.s[1], rng.g.s[2], rng.g.s[3]);
             }
         }
-        // compact the survivors of this wave into the next queue: ballot + prefix sum, one atomic per wave
+        // compact the survivors of this wave into the next queue: ballot + prefix sum, one atomic per wave, on the counter of
+        // the sub-queue this wave slot belongs to (rt_device_types.h, WF_STRIPES)
         const unsigned long long m = __ballot(survive);
         if (m != 0ull) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             uint32_t obase = 0;
             const int leader = __ffsll((long long)m) - 1;
+            const uint32_t stripe = (uint32_t)__builtin_amdgcn_readfirstlane((int)(jq >> 6)) % WF_STRIPES;
             if ((int)(threadIdx.x & 63u) == leader)
-                obase = atomicAdd(L.counters + WF_CNT_OUT, (uint32_t)__popcll(m));
+                obase = wf_stripe_base(stripe, n_slots) + atomicAdd(L.stripes + stripe * WF_STRIPE_WORDS, (uint32_t)__popcll(m));
             obase = __shfl(obase, leader);
             if (survive) {
                 float4 *rw = reinterpret_cast<float4 *>(L.paths_out + obase + rank);
@@ -436,7 +451,17 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
                 *reinterpret_cast<uint4 *>(rw + 3) = nrng;
             }
         }
+        SD_STAMP(SD_STORE);
     }
+#ifdef RT_DIAG_SHADE
+    __syncthreads();
+    if (threadIdx.x < 4u * SD_N && L.diag) { // census words 0..7: cycles per section, 8..15: active lanes, 16..23: stamps (summed over waves)
+        unsigned long long *dg = reinterpret_cast<unsigned long long *>(L.diag);
+        atomicAdd(dg + (threadIdx.x % SD_N), (&g_sd_cyc[0][0])[threadIdx.x]);
+        atomicAdd(dg + 8 + (threadIdx.x % SD_N), (&g_sd_lanes[0][0])[threadIdx.x]);
+        atomicAdd(dg + 16 + (threadIdx.x % SD_N), (&g_sd_cnt[0][0])[threadIdx.x]);
+    }
+#endif
     st.flush(L.stats);
 }
 
@@ -451,9 +476,29 @@ DEV uint32_t spread3(uint32_t v) { // 6 bits -> every third bit
     v = (v | (v << 2)) & 0x09249u;
     return v;
 }
-__global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLaunch L, uint32_t n) {
+// `direct`: no sort follows (sorting off or a tiny queue): the identity order over the dense index goes straight to sort_vals[1].
+// Either way this pass turns the dense ray index j < n into the physical slot of paths_in (sub-queue regions, WF_STRIPES).
+__global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLaunch L, int direct) {
+    __shared__ uint32_t s_run[WF_STRIPES + 1u];
+    const uint32_t n = L.counters[WF_CNT_IN], n_slots = L.counters[WF_CNT_SLOTS];
+    if (threadIdx.x <= WF_STRIPES)
+        s_run[threadIdx.x] = L.stripes[WF_STRIPES * WF_STRIPE_WORDS + threadIdx.x];
+    __syncthreads();
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
+        uint32_t pos = j;
+        if (n_slots != 0u) { // run k holds dense indices [s_run[k], s_run[k+1])
+            uint32_t k = 0;
+#pragma unroll
+            for (uint32_t step = WF_STRIPES / 2u; step != 0u; step >>= 1)
+                if (s_run[k + step] <= j)
+                    k += step;
+            pos = wf_stripe_base(k, n_slots) + (j - s_run[k]);
+        }
+        if (direct) {
+            L.sort_vals[1][j] = pos;
+            continue;
+        }
+        const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + pos);
         const float4 r0 = rq[0], r1 = rq[1];
         const float fx = (r0.x - S.bounds_lo[0]) * S.bounds_inv[0], fy = (r0.y - S.bounds_lo[1]) * S.bounds_inv[1], fz = (r0.z - S.bounds_lo[2]) * S.bounds_inv[2];
         const uint32_t cx = (uint32_t)fminf(fmaxf(fx * 64.0f, 0.0f), 63.0f), cy = (uint32_t)fminf(fmaxf(fy * 64.0f, 0.0f), 63.0f), cz = (uint32_t)fminf(fmaxf(fz * 64.0f, 0.0f), 63.0f);
@@ -473,15 +518,29 @@ __global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLa
             key = (((morton << 3) | oct) << 3) | sub;
         }
         L.sort_keys[0][j] = key;
-        L.sort_vals[0][j] = j;
+        L.sort_vals[0][j] = pos;
     }
 }
 
-// next bounce: the out queue becomes the in queue (the host swaps the pointers)
-__global__ void wf_advance(uint32_t *counters) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        counters[WF_CNT_IN] = counters[WF_CNT_OUT];
-        counters[WF_CNT_OUT] = 0;
+// next bounce: the out queue becomes the in queue (the host swaps the pointers). The sub-queue fill counters turn into the
+// dense prefix run_start[] the ray-order pass reads, and are cleared for the next wf_shade. One wave.
+__global__ __launch_bounds__(64) void wf_advance(uint32_t *counters, uint32_t *stripes) {
+    const uint32_t k = threadIdx.x; // == WF_STRIPES lanes
+    const uint32_t c = stripes[k * WF_STRIPE_WORDS];
+    uint32_t incl = c;
+#pragma unroll
+    for (uint32_t d = 1; d < WF_STRIPES; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (k >= d)
+            incl += up;
+    }
+    uint32_t *run_start = stripes + WF_STRIPES * WF_STRIPE_WORDS;
+    run_start[k] = incl - c;
+    stripes[k * WF_STRIPE_WORDS] = 0u;
+    if (k == WF_STRIPES - 1u) {
+        run_start[WF_STRIPES] = incl;
+        counters[WF_CNT_SLOTS] = (counters[WF_CNT_IN] + 63u) >> 6; // wave slots of the launch that just wrote the new in-queue
+        counters[WF_CNT_IN] = incl;
         counters[WF_CNT_TICKET] = 0;
     }
 }
@@ -533,33 +592,40 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
     hipError_t e = hipMemsetAsync(L.counters, 0, sizeof(uint32_t) * WF_CNT_WORDS, stream);
     if (e != hipSuccess)
         return e;
+    if ((e = hipMemsetAsync(L.stripes, 0, sizeof(uint32_t) * WF_STRIPE_BUF_WORDS, stream)) != hipSuccess)
+        return e;
     if (stats)
         WF_LAUNCH((wf_generate<true>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
     else
         WF_LAUNCH((wf_generate<false>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
     const int ext_blocks = (int)(L.stack_stride / 256u); // rt_scene.cpp sizes the overflow workspace for exactly this grid
-    const int shade_blocks = num_cus * 8;
+    const int shade_blocks = num_cus * RT_SHADE_BLOCKS_PER_CU;
     uint32_t *h_count = L.host_count; // pinned word owned by the scene: per-bounce queue size read-back
     uint32_t n_active = L.n_paths;
     for (uint32_t b = 0; b < L.ray_depth; ++b) {
-        L.order = nullptr;
-        if (b > 0 && L.sort_keys[0] && h_count) { // primary rays are coherent as generated
-            if ((e = hipMemcpyAsync(h_count, L.counters + WF_CNT_IN, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
-                return e;
-            if ((e = hipStreamSynchronize(stream)) != hipSuccess)
-                return e;
-            n_active = *h_count;
-            if (n_active == 0)
-                break;
-            if (n_active >= 4096u) {
-                const uint32_t kb = (n_active + 255u) / 256u < (uint32_t)num_cus * 16u ? (n_active + 255u) / 256u : (uint32_t)num_cus * 16u;
-                WF_LAUNCH(wf_sort_keys, dim3(kb), block, 0, stream, S, L, n_active);
+        L.order = nullptr; // primary rays: dense and coherent as generated
+        if (b > 0) {
+            bool sort = false;
+            if (h_count) {
+                if ((e = hipMemcpyAsync(h_count, L.counters + WF_CNT_IN, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+                    return e;
+                if ((e = hipStreamSynchronize(stream)) != hipSuccess)
+                    return e;
+                n_active = *h_count;
+                if (n_active == 0)
+                    break;
+                sort = L.sort_mode != 0u && n_active >= 4096u;
+            }
+            // dense ray index -> slot of paths_in (wf_shade's sub-queue regions), with the coherence keys when a sort follows
+            const uint32_t kb = (n_active + 255u) / 256u < (uint32_t)num_cus * 16u ? (n_active + 255u) / 256u : (uint32_t)num_cus * 16u;
+            WF_LAUNCH(wf_sort_keys, dim3(kb > 0 ? kb : 1), block, 0, stream, S, L, sort ? 0 : 1);
+            if (sort) {
                 size_t tmp = L.sort_temp_bytes;
                 hipError_t se = rocprim::radix_sort_pairs(L.sort_temp, tmp, L.sort_keys[0], L.sort_keys[1], L.sort_vals[0], L.sort_vals[1], (size_t)n_active, 0u, L.sort_mode == 4 ? 24u : 21u, stream);
                 if (se != hipSuccess)
                     return se;
-                L.order = L.sort_vals[1];
             }
+            L.order = L.sort_vals[1];
         }
         // time the dominant kernel per launch (bench.py roofline): HIP events on the launch stream, taken from the scene's
         // pool (created once, reused by every render)
@@ -579,7 +645,7 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
             WF_LAUNCH((wf_shade<true>), dim3(shade_blocks), block, 0, stream, S, L);
         else
             WF_LAUNCH((wf_shade<false>), dim3(shade_blocks), block, 0, stream, S, L);
-        WF_LAUNCH(wf_advance, dim3(1), dim3(64), 0, stream, L.counters);
+        WF_LAUNCH(wf_advance, dim3(1), dim3(64), 0, stream, L.counters, L.stripes);
         WfPath *t = L.paths_in;
         L.paths_in = L.paths_out;
         L.paths_out = t;

@@ -28,7 +28,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     # the line must say what `achieved` is, where `traffic` comes from (or why it is null), and carry the PMC-derived keys
-    for k in ("achieved_is", "traffic_source", "hbm_rate", "hbm_frac", "request_rate_Greq_s", "request_roof_Greq_s", "request_frac", "limiter", "pmc",
+    for k in ("achieved_is", "traffic_source", "hbm_rate", "hbm_frac", "request_rate_Greq_s", "request_roof_Greq_s", "request_frac", "l1_frac", "limiter", "pmc",
               "peak_measured_read", "peak_measured_source", "kernel", "kernel_src_sha16", "launches_per_step", "avg_launch_ms", "algorithmic_bytes_per_launch", "pipeline"):
         assert k in rf, k
     assert "ALGORITHMIC" in rf["achieved_is"] and len(rf["kernel_src_sha16"]) == 16

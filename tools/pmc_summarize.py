@@ -88,6 +88,19 @@ for kern, short in (("wf_extend<false>", "wf_extend"), ("wf_shade<false>", "wf_s
         d["salu_per_valu"] = round(g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU"), 3)
     if g("TCP_TOTAL_CACHE_ACCESSES_sum"):
         d["l1_hit"] = round(1.0 - g("TCP_TCC_READ_REQ_sum") / g("TCP_TOTAL_CACHE_ACCESSES_sum"), 4)
+        # vector-L1 (TCP) access rate against its measured roof (profiles/r02_l1_roof.txt: a CU's L1 retires <= ~0.98 tag
+        # accesses per clock; a 16-byte-per-lane load costs one access per lane whose line differs from its neighbours').
+        # Shader clock from the pass that carries GRBM_GUI_ACTIVE (summed over the 8 XCDs) and its own kernel time.
+        if g("GRBM_GUI_ACTIVE") and dur.get("GRBM_GUI_ACTIVE") and dur.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            clk_per_ms = g("GRBM_GUI_ACTIVE") / 8.0 / dur["GRBM_GUI_ACTIVE"]
+            d["shader_clock_ghz"] = round(clk_per_ms / 1e6, 3)
+            d["l1_accesses_per_clk_per_cu"] = round(g("TCP_TOTAL_CACHE_ACCESSES_sum") / 256.0 / (dur["TCP_TOTAL_CACHE_ACCESSES_sum"] * clk_per_ms), 4)
+            d["l1_roof_accesses_per_clk_per_cu"] = 0.98
+            d["l1_frac"] = round(d["l1_accesses_per_clk_per_cu"] / 0.98, 4)
+            d["l1_roof_source"] = "profiles/r02_l1_roof.txt (tools/l1_roof_probe.sh: gather of 128-B records, 16-B loads, L2-resident table)"
+            d["l1_miss_rate_Greq_s"] = round(g("TCP_TCC_READ_REQ_sum") / dur["TCP_TCC_READ_REQ_sum"] / 1e6, 2) if dur.get("TCP_TCC_READ_REQ_sum") else None
+            if g("TCP_PENDING_STALL_CYCLES_sum"):
+                d["l1_pending_stall_frac"] = round(g("TCP_PENDING_STALL_CYCLES_sum") / 256.0 / (dur["TCP_PENDING_STALL_CYCLES_sum"] * clk_per_ms), 4)
     if g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
         d["l2_hit"] = round(g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), 4)
     if g("TCC_EA0_WRREQ_sum"):
@@ -97,6 +110,11 @@ for kern, short in (("wf_extend<false>", "wf_extend"), ("wf_shade<false>", "wf_s
     if vb is not None:
         d["limiter"] = (f"latency/issue: VALU issue {vb * 100:.0f} % of slots at {la} of 64 lanes, waves waiting {wa * 100 if wa else 0:.0f} % of their cycles, "
                         f"L2 hit {d.get('l2_hit')}; not HBM bandwidth (see hbm_frac)")
+        if d.get("l1_frac") is not None and d["l1_frac"] >= 0.6:
+            d["limiter"] = (f"vector-L1 access rate: {d['l1_accesses_per_clk_per_cu']} tag accesses per clock per CU = {d['l1_frac']:.2f} of the measured 0.98 roof "
+                            f"(4 accesses per 64-B node per lane), {d.get('l1_pending_stall_frac', 0) * 100:.0f} % of L1 cycles stalled on pending misses; "
+                            f"VALU issue {vb * 100:.0f} % at {la} of 64 lanes, waves waiting {wa * 100 if wa else 0:.0f} %, L1 hit {d.get('l1_hit')}, L2 hit {d.get('l2_hit')}; "
+                            "not HBM bandwidth (see hbm_frac)")
     path = os.path.join(O, f"{tag}_pmc_{short}_{wl}.json")
     json.dump(d, open(path, "w"), indent=1)
     print(short, json.dumps({k: v for k, v in d.items() if k != "raw"}, indent=1))
