@@ -675,7 +675,15 @@ template <class STK> DEV void trav_pop_wave(Trav &T, STK &stk) {
 }
 // bvh_mix_dist::pdf (raytracer.h:363-375) = BVH::foreach_intersection (bvh.h:237-260) over the light BVH summing
 // triangle_dist::pdf_at (raytracer.h:255-261) in DFS order (node objects, left subtree, right subtree).
-template <bool STATS, class STK> DEV float lights_pdf(const DevScene &S, V3 x, V3 d, STK &stk, LaneStats<STATS> &st) {
+// Where the light BVH is read from: its device arrays, or the copy wf_shade stages in LDS when the tree is small
+// (DevBvh::lds_inner). The records are the same 16-byte pieces either way.
+struct LightTabs {
+    const float4 *nodes, *tris, *aux; // DevNode = 4, DevTri = 3, DevLightAux = 1 pieces per record
+};
+DEV LightTabs light_tabs_global(const DevScene &S) {
+    return LightTabs{reinterpret_cast<const float4 *>(S.lights.nodes), reinterpret_cast<const float4 *>(S.lights.tris), reinterpret_cast<const float4 *>(S.light_aux)};
+}
+template <bool STATS, class STK> DEV float lights_pdf(const DevScene &S, const LightTabs &LT, V3 x, V3 d, STK &stk, LaneStats<STATS> &st) {
     const DevBvh &bvh = S.lights;
     st.lq();
     float res = 0;
@@ -686,7 +694,7 @@ template <bool STATS, class STK> DEV float lights_pdf(const DevScene &S, V3 x, V
         const V3 r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         while (cur != T_DONE) {
             const bool leaf = (cur & RT_LEAF_FLAG) != 0;
-            const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (cur & RT_LEAF_BEGIN_MASK)) : reinterpret_cast<const float4 *>(bvh.nodes + cur);
+            const float4 *p = leaf ? LT.tris + 3u * (cur & RT_LEAF_BEGIN_MASK) : LT.nodes + 4u * cur;
             const float4 r0 = p[0], r1 = p[1], r2 = p[2];
             if (!leaf) {
                 const float4 r3 = p[3];
@@ -721,7 +729,7 @@ template <bool STATS, class STK> DEV float lights_pdf(const DevScene &S, V3 x, V
                 V3 xs;
                 if (tri_hit(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), x, d, EPS, xs)) {
                     st.lhit();
-                    const float4 aux = *reinterpret_cast<const float4 *>(S.light_aux + k);
+                    const float4 aux = LT.aux[k];
                     V3 y = x + d * xs.z;  // ray.at(t)
                     V3 dir = norm(y - x); // raytracer.h:259
                     float mult = len2(x - y) / __builtin_fabsf(dot(dir, mk(aux.x, aux.y, aux.z))); // :79-84
@@ -989,7 +997,7 @@ struct ShadeResult {
     V3 term, emission, scl, nro, nrd;
 };
 template <class R, bool STATS, class STK>
-DEV ShadeResult shade_hit(const DevScene &S, const Hit &h, V3 ro, V3 rd, R &rng, bool has_lights, STK &stk, const float *s_lin,
+DEV ShadeResult shade_hit(const DevScene &S, const LightTabs &LT, const Hit &h, V3 ro, V3 rd, R &rng, bool has_lights, STK &stk, const float *s_lin,
                           const float *s_gam, LaneStats<STATS> &st) {
     ShadeResult out;
     out.terminal = false;
@@ -1020,14 +1028,15 @@ DEV ShadeResult shade_hit(const DevScene &S, const Hit &h, V3 ro, V3 rd, R &rng,
             dir = norm(ii.normal + sphere_uniform(rng));
         } else { // bvh_mix_dist::sample :353-361 + triangle_dist::sample :225-239
             const uint32_t id = rng.below(S.lights.n_tris);
-            const DevTri lt = load_tri(S.lights.tris, id);
+            const float4 *lp = LT.tris + 3u * id;
+            const float4 l0 = lp[0], l1 = lp[1], l2 = lp[2];
             float u = uniform_real(rng, 0, 1);
             float v = uniform_real(rng, 0, 1);
             if (u + v > 1) {
                 u = 1 - u;
                 v = 1 - v;
             }
-            V3 p = ld3(lt.a) + ld3(lt.v) * v + ld3(lt.u) * u;
+            V3 p = mk(l0.x, l0.y, l0.z) + mk(l0.w, l1.x, l1.y) * v + mk(l1.z, l1.w, l2.x) * u; // a + v' * v + u' * u (DevTri: a, v, u)
             dir = norm(p - pos);
         }
     }
@@ -1045,7 +1054,7 @@ DEV ShadeResult shade_hit(const DevScene &S, const Hit &h, V3 ro, V3 rd, R &rng,
     } else { // mix_dist::pdf :395-407
         float r = 0;
         r += cos_p;
-        r += lights_pdf<STATS>(S, pos, dir, stk, st);
+        r += lights_pdf<STATS>(S, LT, pos, dir, stk, st);
         MIS_p = r / 2.0f;
         SD_STAMP(SD_PDF_LIGHTS);
     }

@@ -92,8 +92,9 @@ struct DevBvh {
     uint32_t root;   // RT_NONE (no objects at all), inner index, or RT_LEAF_FLAG|0
     uint32_t n_tris; // BVH::objects.size()
     uint32_t fast_ok; // every node box coordinate is 0 or has magnitude in [2^-37, 2^40] (div_exact_fast precondition)
-    uint32_t pad;
+    uint32_t lds_inner; // light BVH only: 0, or 1 + number of inner nodes when nodes + triangles + aux fit RT_SHADE_LIGHTS_F4 (wf_shade stages them in LDS)
 };
+#define RT_SHADE_LIGHTS_F4 384 /* 6 KB of LDS in wf_shade: 4 pieces per inner node + 4 per light triangle (e.g. 31 nodes + 64 lights) */
 
 struct DevScene {
     DevBvh scene;

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const De
                 prims_closest(S, T.o, T.d, h);
             if (h.k != RT_NONE)
                 depth_left -= 1; // shade(..., max_depth - 1)
-            const ShadeResult sr = shade_hit<Rng<MODE>, STATS>(S, h, T.o, T.d, rng, has_lights, stk, s_lin, s_gam, st);
+            const ShadeResult sr = shade_hit<Rng<MODE>, STATS>(S, light_tabs_global(S), h, T.o, T.d, rng, has_lights, stk, s_lin, s_gam, st);
             bool terminal = sr.terminal;
             V3 term = sr.term;
             const V3 nro = sr.nro, nrd = sr.nrd;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void light_pdf_kernel(const DevScene S, const 
     RT_DECLARE_STACK(stk, LDS_DEPTH, s_stack);
     LaneStats<false> st;
     V3 o = ld3(rays + 6ull * i), d = ld3(rays + 6ull * i + 3);
-    pdf_out[i] = S.lights.n_tris ? lights_pdf<false>(S, o, d, stk, st) : 0.0f;
+    pdf_out[i] = S.lights.n_tris ? lights_pdf<false>(S, light_tabs_global(S), o, d, stk, st) : 0.0f;
 }
 
 } // namespace

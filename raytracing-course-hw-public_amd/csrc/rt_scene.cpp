@@ -222,6 +222,17 @@ extern "C" int rt_device_count(void) {
     return n;
 }
 
+// wf_shade stages a small light BVH in LDS (rt_wavefront.hip, LIGHTS_LDS): 0 when it does not fit RT_SHADE_LIGHTS_F4 pieces
+// (or RT_LIGHTS_LDS=0), else 1 + number of inner nodes.
+static uint32_t light_lds_inner(const rt::FlatBvh &f) {
+    if (const char *e = getenv("RT_LIGHTS_LDS"))
+        if (e[0] == '0')
+            return 0u;
+    if (f.root == RT_NONE || f.tris.empty() || 4u * f.nodes.size() + 4u * f.tris.size() > (size_t)RT_SHADE_LIGHTS_F4)
+        return 0u;
+    return (uint32_t)f.nodes.size() + 1u;
+}
+
 static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -472,6 +483,7 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
         b.root = flat[w].root;
         b.n_tris = (uint32_t)flat[w].tris.size();
         b.fast_ok = flat[w].fast_ok ? 1u : 0u;
+        b.lds_inner = w == 1 ? light_lds_inner(flat[w]) : 0u;
         s->dev_n_inner[w] = (uint32_t)flat[w].nodes.size();
     }
     if (dev_build)

@@ -350,10 +350,24 @@ __global__ __launch_bounds__(256) void wf_extend_prims(const DevScene S, const W
 }
 
 // ------------------------------------------------------------------------------------------------ shade
-template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD) void wf_shade(const DevScene S, const WfLaunch L) {
+// LIGHTS_LDS: the light BVH (inner nodes, triangles, aux) is small enough (DevBvh::lds_inner) to be staged in LDS once per
+// block; bvh_mix_dist's sample and pdf then read it there: a dozen dependent L1 round trips per hit become LDS reads.
+template <bool STATS, bool LIGHTS_LDS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD) void wf_shade(const DevScene S, const WfLaunch L) {
     __shared__ float s_lin[256];
     __shared__ float s_gam[256];
     __shared__ uint32_t s_stack[STACK_LDS_DWORDS_FOR(RT_SHADE_LDS_DEPTH)];
+    __shared__ float4 s_lights[LIGHTS_LDS ? RT_SHADE_LIGHTS_F4 : 1];
+    LightTabs LT = light_tabs_global(S);
+    if (LIGHTS_LDS) {
+        const uint32_t n_node_f4 = 4u * (S.lights.lds_inner - 1u), n_tri_f4 = 3u * S.lights.n_tris;
+        for (uint32_t i = threadIdx.x; i < n_node_f4; i += blockDim.x)
+            s_lights[i] = LT.nodes[i];
+        for (uint32_t i = threadIdx.x; i < n_tri_f4; i += blockDim.x)
+            s_lights[n_node_f4 + i] = LT.tris[i];
+        for (uint32_t i = threadIdx.x; i < S.lights.n_tris; i += blockDim.x)
+            s_lights[n_node_f4 + n_tri_f4 + i] = LT.aux[i];
+        LT = LightTabs{s_lights, s_lights + n_node_f4, s_lights + n_node_f4 + n_tri_f4};
+    }
     s_lin[threadIdx.x] = S.lut_linear[threadIdx.x];
     s_gam[threadIdx.x] = S.lut_gamma[threadIdx.x];
 #ifdef RT_DIAG_SHADE
@@ -391,7 +405,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD)
             if (h.k != RT_NONE)
                 depth_left -= 1; // shade(..., max_depth - 1)
             SD_STAMP(SD_LOAD);
-            const ShadeResult sr = shade_hit<Rng<RT_RNG_DEVICE>, STATS>(S, h, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), rng, has_lights, stk, s_lin, s_gam, st);
+            const ShadeResult sr = shade_hit<Rng<RT_RNG_DEVICE>, STATS>(S, LT, h, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), rng, has_lights, stk, s_lin, s_gam, st);
             SD_STAMP(SD_BRDF);
             bool terminal = sr.terminal;
             V3 term = sr.term;
@@ -641,10 +655,15 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
             (void)hipEventRecord(e1, stream);
         if (S.n_prims)
             WF_LAUNCH(wf_extend_prims, dim3(shade_blocks), block, 0, stream, S, L);
-        if (stats)
-            WF_LAUNCH((wf_shade<true>), dim3(shade_blocks), block, 0, stream, S, L);
+        const bool lights_lds = S.lights.lds_inner != 0u;
+        if (stats && lights_lds)
+            WF_LAUNCH((wf_shade<true, true>), dim3(shade_blocks), block, 0, stream, S, L);
+        else if (stats)
+            WF_LAUNCH((wf_shade<true, false>), dim3(shade_blocks), block, 0, stream, S, L);
+        else if (lights_lds)
+            WF_LAUNCH((wf_shade<false, true>), dim3(shade_blocks), block, 0, stream, S, L);
         else
-            WF_LAUNCH((wf_shade<false>), dim3(shade_blocks), block, 0, stream, S, L);
+            WF_LAUNCH((wf_shade<false, false>), dim3(shade_blocks), block, 0, stream, S, L);
         WF_LAUNCH(wf_advance, dim3(1), dim3(64), 0, stream, L.counters, L.stripes);
         WfPath *t = L.paths_in;
         L.paths_in = L.paths_out;
