@@ -65,7 +65,7 @@ else:
     print("no FETCH_SIZE/WRITE_SIZE data", dict(agg))
 
 # ---- SQ / TCP / TCC counters
-for kern, short in (("wf_extend<false>", "wf_extend"), ("wf_shade<false>", "wf_shade")):
+for kern, short in (("wf_extend<false>", "wf_extend"), ("wf_shade<false", "wf_shade")):
     agg, dur, n = collect(f"{tag}_pmc_sq*_{wl}", kern)
     if not agg:
         print("no SQ data for", kern)
