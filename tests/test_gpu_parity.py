@@ -4,6 +4,8 @@ Bar (BASELINE north_star): bit-exact primitive-hit indices; per-pixel radiance w
 kernels evaluate the same IEEE operation sequence as the oracle, so most comparisons below demand bit equality and
 only the framebuffer test states the 1e-5 tolerance.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -120,6 +122,29 @@ def test_render_device_rng_matches_oracle(pairs, gpu, name):
               "light_tri_tests", "light_hits", "texel_fetches"):
         assert gst[k] == ost[k], f"counter {k}: gpu {gst[k]} oracle {ost[k]}"
     assert np.array_equal(gpu.tonemap(gfb), gpu.tonemap(ofb))
+
+
+@pytest.mark.parametrize("shape", [(5, 3, 1), (17, 13, 3), (64, 64, 1), (80, 60, 1), (96, 50, 2), (33, 31, 7)])
+def test_queue_shapes_match_oracle(pairs, gpu, shape):
+    """wf_shade appends to 64 sub-queues whose regions are whole wave slots; the next bounce maps the dense ray index back to
+    a slot (with a sort from 4096 rays up, directly below). Path counts below one wave, not multiples of 64, exactly at and
+    across the 4096-ray sort threshold (a queue that shrinks below it between bounces) all give the oracle's framebuffer
+    bit for bit, with sorting on and off."""
+    dev, orc, _ = pairs["room_manylights"]
+    W, H, SPP = shape
+    ofb, ost = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=99)
+    for sort in ("4", "0"):
+        old = os.environ.get("RT_WF_SORT")
+        os.environ["RT_WF_SORT"] = sort
+        try:
+            gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=99, counters=True)
+        finally:
+            if old is None:
+                os.environ.pop("RT_WF_SORT", None)
+            else:
+                os.environ["RT_WF_SORT"] = old
+        assert np.array_equal(gfb.view(np.uint32), ofb.view(np.uint32)), (shape, sort)
+        assert gst["samples"] == ost["samples"] == W * H * SPP and gst["casts"] == ost["casts"] and gst["shaded_hits"] == ost["shaded_hits"]
 
 
 @pytest.mark.parametrize("name", ["room_plain", "room_textured", "room_manylights"])
