@@ -649,6 +649,48 @@ template <bool STATS, class STK> DEV void trav_step_inner_fast(Trav &T, const De
     T.t_loc = both ? RT_NAN : T.t_loc;
     T.cur = both ? (swap ? right : left) : (hl ? left : (hr ? right : T_POP));
 }
+// The same node step on a record the caller already holds (wf_extend_packet: one scalar fetch serves every lane standing on
+// the node). Guarded rays (T.fast false) take the reference division; the bookkeeping is trav_step_inner_fast's.
+template <bool STATS, class STK>
+DEV void trav_inner_apply(Trav &T, STK &stk, V3 lmin, V3 lmax, V3 rmn, V3 rmx, uint32_t left, uint32_t right, float min_dst, LaneStats<STATS> &st) {
+    st.node();
+    st.box(2);
+    float dl, dr;
+    bool hl, hr;
+    if (T.fast) {
+        hl = box_hit_fast(lmin, lmax, T.o, T.d, T.r, min_dst, dl);
+        hr = box_hit_fast(rmn, rmx, T.o, T.d, T.r, min_dst, dr);
+    } else {
+        hl = box_hit_exact(lmin, lmax, T.o, T.d, min_dst, dl);
+        hr = box_hit_exact(rmn, rmx, T.o, T.d, min_dst, dr);
+    }
+    const bool both = hl & hr;
+    const bool swap = dl > dr; // bvh.h:216 (ties keep left first)
+    if (both & (T.sp > 0))
+        stk.push(T.sp - 1, T.top_ref, T.top_d, T.top_loc); // spill the previous top
+    T.top_ref = both ? (swap ? left : right) : T.top_ref;
+    T.top_d = both ? (swap ? dl : dr) : T.top_d;
+    T.top_loc = both ? T.t_loc : T.top_loc;
+    T.sp += both ? 1 : 0;
+    T.t_loc = both ? RT_NAN : T.t_loc;
+    T.cur = both ? (swap ? right : left) : (hl ? left : (hr ? right : T_POP));
+}
+// Scalar (s_load) reads of scene constants at a wave-uniform address: the constant address space tells the compiler that
+// nothing in the kernel writes them.
+typedef float F4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) F4v *ConstF4;
+DEV ConstF4 as_const_f4(const void *p) { return (ConstF4)(unsigned long long)p; }
+// minimum of a value over the 64 lanes of a fully active wave (row shifts, then the two row broadcasts of gfx9 DPP)
+DEV uint32_t wave_min_u32(uint32_t v) {
+    const int id = -1; // 0xFFFFFFFF: what a lane without a source reads
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x111, 0xF, 0xF, false)); // row_shr:1
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x112, 0xF, 0xF, false)); // row_shr:2
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x114, 0xF, 0xF, false)); // row_shr:4
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x118, 0xF, 0xF, false)); // row_shr:8 -> lane 15 of a row = row minimum
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x142, 0xA, 0xF, false)); // row_bcast:15 into rows 1 and 3
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x143, 0xC, 0xF, false)); // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 // one unwind step for every lane in T_POP, as straight-line wave code (lanes in other states pass through unchanged)
 template <class STK> DEV void trav_pop_once(Trav &T, STK &stk) {
     DIAG(7, 1);

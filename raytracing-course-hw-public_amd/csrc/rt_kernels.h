@@ -44,8 +44,9 @@ hipError_t launch_cast(const DevScene &S, const float *rays, uint32_t n, uint32_
 hipError_t launch_light_pdf(const DevScene &S, const float *rays, uint32_t n, float *pdf, hipStream_t stream);
 // rt_wavefront.hip: one pass (pixel tile x sample range) of the wavefront pipeline, stream-ordered
 // `extend_events` (optional): one (start, stop) event pair per wf_extend launch is taken from the pool and recorded on `stream`
+// `packet_census_out` (optional, host, 2 words): trips and lanes served of this pass's wf_extend_packet launch (0, 0 if it did not run)
 hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int num_cus, bool first_pass, bool last_pass, hipStream_t stream,
-                                 EventPool *extend_events);
+                                 EventPool *extend_events, unsigned long long *packet_census_out);
 // bytes of temporary storage rocPRIM's radix sort needs for `n` (key, slot) pairs
 size_t wavefront_sort_temp_bytes(size_t n);
 } // namespace rt

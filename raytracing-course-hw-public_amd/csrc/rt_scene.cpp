@@ -144,7 +144,11 @@ struct rt_scene {
     uint32_t *wf_sort_keys[2] = {nullptr, nullptr}, *wf_sort_vals[2] = {nullptr, nullptr};
     void *wf_sort_temp = nullptr;
     size_t wf_sort_temp_bytes = 0;
-    uint32_t *wf_host_count = nullptr; // pinned
+    uint32_t *wf_host_count = nullptr; // pinned, 8 words: [0] queue size, [2..5] wf_extend_packet's census
+    // wf_extend_packet (primary rays as coherent packets) pays off only while a wave's 64 rays stay together; its own census
+    // (lanes served per trip) decides per configuration whether later passes and renders keep using it
+    uint64_t pkt_key = 0; // width, height, samples per pass, shard count of the configuration pkt_off was measured on
+    bool pkt_off = false;
 
     int ensure_wavefront(uint64_t paths, uint64_t pixels, uint32_t depth) {
         if (paths <= wf_paths_cap && pixels <= wf_pixels_cap && depth <= wf_depth_cap)
@@ -729,12 +733,18 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
             W.sort_keys[k] = s->wf_sort_keys[k];
             W.sort_vals[k] = s->wf_sort_vals[k];
         }
-        if (!s->wf_host_count && hipHostMalloc((void **)&s->wf_host_count, sizeof(uint32_t)) != hipSuccess)
+        if (!s->wf_host_count && hipHostMalloc((void **)&s->wf_host_count, 8 * sizeof(uint32_t)) != hipSuccess)
             s->wf_host_count = nullptr;
         W.host_count = s->wf_host_count;
         W.sort_temp = s->wf_sort_temp;
         W.sort_mode = sort_env ? (uint32_t)std::atoi(sort_env) : 4u; // 24-bit key: cell, octant, direction sub-cone (measured best)
         W.sort_temp_bytes = s->wf_sort_temp_bytes;
+        // primary rays as packets (wf_extend_packet): RT_WF_PACKET=0 never, =1 always; default: from 16 samples per pixel and pass
+        // up, until the kernel's census says its packets fall apart (fewer than 33 of 64 lanes served per trip: the measured
+        // break-even against wf_extend, profiles/r02_packet.txt) for this image size / samples per pass
+        const char *pkt_env = std::getenv("RT_WF_PACKET");
+        const int pkt_mode = pkt_env ? std::atoi(pkt_env) : -1;
+        W.packet_census = reinterpret_cast<unsigned long long *>(s->wf_counters + 32);
         W.stats = L.stats;
         for (uint64_t p0 = 0; p0 < local_pixels; p0 += tile_pixels) {
             W.first_pixel = (uint32_t)p0;
@@ -743,8 +753,17 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
                 W.first_sample = s0;
                 W.pass_samples = std::min<uint32_t>(pass_spp, p->samples - s0);
                 W.n_paths = W.pass_pixels * W.pass_samples;
+                const uint64_t key = ((uint64_t)p->width << 44) ^ ((uint64_t)p->height << 24) ^ ((uint64_t)W.pass_samples << 8) ^ (uint64_t)L.shard_count;
+                if (key != s->pkt_key) {
+                    s->pkt_key = key;
+                    s->pkt_off = false;
+                }
+                W.use_packet = pkt_mode == 0 ? 0u : pkt_mode > 0 ? 1u : (W.pass_samples >= 16u && !s->pkt_off) ? 1u : 0u;
+                unsigned long long census[2] = {0ull, 0ull};
                 HIP_TRY(rt::launch_wavefront_pass(s->dev, W, counters, s->num_cus, s0 == 0, s0 + W.pass_samples >= p->samples, s->stream,
-                                                  stats ? &s->ext_events : nullptr));
+                                                  stats ? &s->ext_events : nullptr, census));
+                if (census[0] != 0ull && (double)census[1] < 33.0 * (double)census[0])
+                    s->pkt_off = true;
             }
         }
     } else if (L.n_items > 0) {

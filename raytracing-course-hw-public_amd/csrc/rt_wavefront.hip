@@ -71,6 +71,10 @@ template <bool STATS> __global__ __launch_bounds__(256) void wf_generate(const D
     const V3 cam_pos = ld3(S.cam_pos), cam_right = ld3(S.cam_right), cam_up = ld3(S.cam_up), cam_fwd = ld3(S.cam_fwd);
     if (blockIdx.x == 0 && threadIdx.x == 0)
         L.counters[WF_CNT_IN] = L.n_paths; // the first bounce's queue is the identity: slot i holds path i
+#ifdef RT_DIAG
+    if (STATS && threadIdx.x == 0 && blockIdx.x == 0)
+        g_diag = (DevStats *)L.diag; // set a launch ahead of the kernels that count
+#endif
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < L.n_paths; i += gridDim.x * blockDim.x) {
         const uint32_t lp = i / L.pass_samples;
         const uint32_t ds = i - lp * L.pass_samples;
@@ -325,6 +329,121 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
         atomicAdd(dg + 26, 1ull);
     }
 #endif
+    st.flush(L.stats);
+}
+
+// ------------------------------------------------------------------------------------------------ extend: coherent packets
+// Primary rays. A wave's 64 queue positions are 64 samples of one pixel (or a few neighbouring pixels): rays that visit almost
+// the same nodes. wf_extend lets its lanes drift apart (each lane refills on its own), so it pays one vector-L1 access per lane
+// and 16-byte piece for them like for any other ray, and the L1 access rate is its roof (profiles/r02_l1_roof.txt). Here the
+// wave stays a packet: all 64 rays start together, and every trip serves ONE record — the smallest pending node or leaf
+// reference over the lanes (inner nodes before leaves, earlier nodes first, so stragglers catch up and lanes re-join) —
+// fetched once through the scalar cache and applied by the lanes standing on it. Each lane still runs its own traversal
+// state machine (trav_inner_apply / the leaf loop of trav_step_core / trav_pop_once, its own stack, its own near/far order
+// and pruning), only WHEN a lane advances is decided per wave: results, order of strict-less replacements and counters are
+// the per-lane kernel's by construction. No vector loads on the traversal path at all.
+#ifndef RT_PKT_CHUNK
+#define RT_PKT_CHUNK 256u /* queue positions per ticket atomic (4 packets) */
+#endif
+template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) void wf_extend_packet(const DevScene S, const WfLaunch L) {
+    __shared__ uint32_t s_stack[STACK_LDS_DWORDS_FOR(RT_EXT_LDS_DEPTH)];
+    LaneStats<STATS> st;
+    RT_DECLARE_RING_STACK(stk, RT_EXT_LDS_DEPTH, s_stack, reinterpret_cast<uint4 *>(L.stack_overflow), L.stack_stride);
+    const uint32_t n_in = L.counters[WF_CNT_IN];
+    const uint32_t lane = threadIdx.x & 63u;
+#ifdef RT_DIAG
+    if (STATS && threadIdx.x == 0 && blockIdx.x == 0)
+        g_diag = (DevStats *)L.diag;
+#endif
+    Trav T;
+    T.o = T.d = T.r = mk(0.f, 0.f, 0.f);
+    T.cur = T_DONE;
+    T.sp = 0;
+    T.t_loc = RT_NAN;
+    T.best = Hit{RT_NONE, 0.f, 0.f, 0.f};
+    T.fast = false;
+    T.top_ref = 0u;
+    T.top_d = T.top_loc = 0.f;
+    unsigned long long n_trips = 0ull, n_lanes = 0ull; // wave-uniform
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0u)
+            base = atomicAdd(L.counters + WF_CNT_TICKET, (uint32_t)RT_PKT_CHUNK);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n_in)
+            break;
+        for (uint32_t q0 = base; q0 < base + RT_PKT_CHUNK && q0 < n_in; q0 += 64u) { // wave-uniform
+            const uint32_t jq = q0 + lane;
+            const bool have = jq < n_in;
+            T.cur = T_DONE;
+            if (have) {
+                const uint32_t j = L.order ? L.order[jq] : jq;
+                const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
+                const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
+                trav_init_stored(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r2.x, r2.y, r2.z), __float_as_uint(r2.w) != 0u);
+                stk.reset();
+            }
+            for (;;) {
+                trav_pop_wave(T, stk); // every lane that has to unwind does, until none is left in T_POP
+                const uint32_t target = wave_min_u32(T.cur); // T_DONE is the largest value a lane can hold here
+                if (target == T_DONE)
+                    break;
+                const bool mine = T.cur == target;
+                const unsigned long long mm = __ballot(mine);
+                if (mm == 0ull) // cannot happen (the minimum is some lane's value); never spin on a wrong reduction
+                    break;
+                ++n_trips; // how coherent the packets are: the host keeps or drops this kernel on lanes per trip
+                n_lanes += (uint32_t)__popcll(mm);
+                DIAG(9, 1); // development census (tools/diag_packet.py): trips, lanes served, leaf trips
+                DIAG(10, (unsigned long long)__popcll(mm));
+                DIAG(11, (target & RT_LEAF_FLAG) ? 1ull : 0ull);
+                if ((target & RT_LEAF_FLAG) == 0u) {
+                    // the record's address must stay a scalar: inside `if (mine)` the compiler knows T.cur == target and would
+                    // otherwise address the node through the lane's own T.cur (a vector load per lane)
+                    uint32_t node_index = target;
+                    asm volatile("" : "+s"(node_index));
+                    ConstF4 p = as_const_f4(S.scene.nodes + node_index);
+                    const F4v r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+                    if (mine)
+                        trav_inner_apply<STATS>(T, stk, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), mk(r2.y, r2.z, r2.w), __float_as_uint(r3.x),
+                                                __float_as_uint(r3.y), EPS, st);
+                } else { // a leaf: its triangles in index order, strict-less replacement (bvh.h:200-204,132)
+                    const uint32_t cnt = RT_LEAF_CNT(target);
+                    uint32_t k = target & RT_LEAF_BEGIN_MASK;
+                    for (uint32_t i = 0;; ++i, ++k) {
+                        ConstF4 p = as_const_f4(S.scene.tris + k);
+                        const F4v r0 = p[0], r1 = p[1], r2 = p[2];
+                        const uint32_t flags = __float_as_uint(r2.z);
+                        if (mine) {
+                            if (flags & 2u)
+                                st.node(); // one BVH::intersect_ray invocation on the leaf node
+                            st.tri();
+                            V3 xs;
+                            if (tri_hit(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), T.o, T.d, EPS, xs)) {
+                                if (T.best.k == RT_NONE || T.best.t > xs.z) {
+                                    T.best.k = k;
+                                    T.best.b = xs.x;
+                                    T.best.c = xs.y;
+                                    T.best.t = xs.z;
+                                }
+                                T.t_loc = fminf(T.t_loc, xs.z);
+                            }
+                        }
+                        if (cnt != 0u ? i + 1u == cnt : (flags & 1u) != 0u)
+                            break;
+                    }
+                    if (mine)
+                        T.cur = T_POP;
+                }
+            }
+            if (have)
+                *reinterpret_cast<float4 *>(L.hits + jq) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
+        }
+    }
+    if (lane == 0u && L.packet_census && n_trips != 0ull) {
+        atomicAdd(L.packet_census, n_trips);
+        atomicAdd(L.packet_census + 1, n_lanes);
+    }
     st.flush(L.stats);
 }
 
@@ -600,7 +719,7 @@ namespace rt {
     } while (0)
 
 hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int num_cus, bool first_pass, bool last_pass, hipStream_t stream,
-                                 EventPool *extend_events) {
+                                 EventPool *extend_events, unsigned long long *packet_census_out) {
     const int gen_blocks = (int)((L.n_paths + 255u) / 256u < (uint32_t)num_cus * 16u ? (L.n_paths + 255u) / 256u : (uint32_t)num_cus * 16u);
     const dim3 block(256);
     hipError_t e = hipMemsetAsync(L.counters, 0, sizeof(uint32_t) * WF_CNT_WORDS, stream);
@@ -608,6 +727,11 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         return e;
     if ((e = hipMemsetAsync(L.stripes, 0, sizeof(uint32_t) * WF_STRIPE_BUF_WORDS, stream)) != hipSuccess)
         return e;
+    const bool packet = L.use_packet != 0u && L.packet_census != nullptr;
+    if (packet && (e = hipMemsetAsync(L.packet_census, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess)
+        return e;
+    if (packet_census_out)
+        packet_census_out[0] = packet_census_out[1] = 0ull;
     if (stats)
         WF_LAUNCH((wf_generate<true>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
     else
@@ -623,8 +747,13 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
             if (h_count) {
                 if ((e = hipMemcpyAsync(h_count, L.counters + WF_CNT_IN, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
                     return e;
+                const bool read_census = b == 1 && packet && packet_census_out; // rides on the queue-size read-back: no extra sync
+                if (read_census && (e = hipMemcpyAsync(h_count + 2, L.packet_census, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+                    return e;
                 if ((e = hipStreamSynchronize(stream)) != hipSuccess)
                     return e;
+                if (read_census)
+                    std::memcpy(packet_census_out, h_count + 2, 2 * sizeof(unsigned long long));
                 n_active = *h_count;
                 if (n_active == 0)
                     break;
@@ -647,7 +776,11 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         hipEvent_t e1 = e0 ? extend_events->next() : nullptr;
         if (e0 && e1)
             (void)hipEventRecord(e0, stream);
-        if (stats)
+        if (b == 0 && packet && stats) // coherent primary rays
+            WF_LAUNCH((wf_extend_packet<true>), dim3(ext_blocks), block, 0, stream, S, L);
+        else if (b == 0 && packet)
+            WF_LAUNCH((wf_extend_packet<false>), dim3(ext_blocks), block, 0, stream, S, L);
+        else if (stats)
             WF_LAUNCH((wf_extend<true>), dim3(ext_blocks), block, 0, stream, S, L);
         else
             WF_LAUNCH((wf_extend<false>), dim3(ext_blocks), block, 0, stream, S, L);
