@@ -13,6 +13,28 @@ from conftest import random_rays
 
 pytestmark = pytest.mark.gpu
 
+
+class _env:
+    """Set environment variables the library reads per render (RT_WF_PACKET, RT_WF_SORT) for the duration of a with-block."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
 REL_TOL = 1e-5  # north_star: per-pixel radiance within 1e-5 relative
 
 
@@ -113,15 +135,17 @@ def test_render_device_rng_matches_oracle(pairs, gpu, name):
     (observed: bit-identical), identical event counters."""
     dev, orc, _ = pairs[name]
     W, H, SPP = 48, 40, 6
-    gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=1234, counters=True)
     ofb, ost = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=1234)
-    assert np.isfinite(gfb).all()
-    err = _rel_err(gfb, ofb)
-    assert err.max() <= REL_TOL, f"max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
-    for k in ("samples", "casts", "nodes_visited", "box_tests", "tri_tests", "shaded_hits", "light_queries", "light_nodes", "light_box_tests",
-              "light_tri_tests", "light_hits", "texel_fetches"):
-        assert gst[k] == ost[k], f"counter {k}: gpu {gst[k]} oracle {ost[k]}"
-    assert np.array_equal(gpu.tonemap(gfb), gpu.tonemap(ofb))
+    for pkt in ("0", "1"): # primary rays per lane (wf_extend) / as packets (wf_extend_packet)
+        with _env(RT_WF_PACKET=pkt):
+            gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=1234, counters=True)
+        assert np.isfinite(gfb).all()
+        err = _rel_err(gfb, ofb)
+        assert err.max() <= REL_TOL, f"max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+        for k in ("samples", "casts", "nodes_visited", "box_tests", "tri_tests", "shaded_hits", "light_queries", "light_nodes", "light_box_tests",
+                  "light_tri_tests", "light_hits", "texel_fetches"):
+            assert gst[k] == ost[k], f"counter {k}: gpu {gst[k]} oracle {ost[k]} (packet {pkt})"
+        assert np.array_equal(gpu.tonemap(gfb), gpu.tonemap(ofb))
 
 
 @pytest.mark.parametrize("shape", [(5, 3, 1), (17, 13, 3), (64, 64, 1), (80, 60, 1), (96, 50, 2), (33, 31, 7)])
@@ -244,12 +268,15 @@ def test_full_size_bench_scene_parity(gpu, oracle, sg):
 def _cmp_render(gpu, oracle, sc, W=40, H=36, SPP=5, seed=3):
     dev, orc = gpu.DeviceScene(sc), oracle.OracleScene(sc)
     try:
-        for kw in ({}, {"megakernel": True}):
-            g, gs = dev.run_raytracer(W, H, SPP, seed=seed, counters=True, **kw)
-            o, os_ = orc.run_raytracer(W, H, SPP, seed=seed)
-            assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), kw
+        # the wavefront pipeline with primary rays through wf_extend (per lane) and through wf_extend_packet (64-ray packets),
+        # then the persistent megakernel: one image, one set of event counts
+        o, os_ = orc.run_raytracer(W, H, SPP, seed=seed)
+        for kw, pkt in (({}, "0"), ({}, "1"), ({"megakernel": True}, None)):
+            with _env(RT_WF_PACKET=pkt):
+                g, gs = dev.run_raytracer(W, H, SPP, seed=seed, counters=True, **kw)
+            assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), (kw, pkt)
             for k in ("casts", "nodes_visited", "box_tests", "tri_tests", "shaded_hits", "texel_fetches", "light_tri_tests"):
-                assert gs[k] == os_[k], (k, kw)
+                assert gs[k] == os_[k], (k, kw, pkt)
         rays = random_rays(sc, 4000, seed=17) if sc.n_triangles else np.random.default_rng(1).normal(size=(100, 6)).astype(np.float32)
         gp, gb = dev.cast_rays(rays)
         op, ob = orc.cast_rays(rays)

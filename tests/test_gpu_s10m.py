@@ -62,6 +62,18 @@ def test_s10m_full_size_parity_and_properties(gpu, oracle, sg):
     assert np.array_equal(a.view(np.uint32), m.view(np.uint32)), "wavefront pipeline != persistent megakernel"
     for k in COUNTERS:
         assert ast[k] == mst[k], k
+    oldp = os.environ.get("RT_WF_PACKET")
+    try:
+        os.environ["RT_WF_PACKET"] = "1"  # primary rays as 64-ray packets (wf_extend_packet) even at 2 SPP: incoherent packets, same hits
+        pk, pst = dev.run_raytracer(W, H, 2, seed=11, counters=True)
+    finally:
+        if oldp is None:
+            os.environ.pop("RT_WF_PACKET", None)
+        else:
+            os.environ["RT_WF_PACKET"] = oldp
+    assert np.array_equal(pk.view(np.uint32), a.view(np.uint32)), "packet traversal of the primary rays != per-lane traversal"
+    for k in COUNTERS:
+        assert pst[k] == ast[k], k
     sh = np.zeros_like(a)
     for r in range(8):
         dev.run_raytracer(W, H, 2, seed=11, shard_index=r, shard_count=8, shard_block=8 * W, out=sh)
