@@ -295,7 +295,7 @@ def main() -> None:
         "pmc": pmc,
         "peak_measured_read": stream_peak,
         "peak_measured_source": stream_src,
-        "kernel": "wf_extend<false>",
+        "kernel": "wf_extend<false> (closest hit; primary rays through wf_extend_packet<false> while its packets stay coherent): every closest-hit launch is timed",
         "kernel_src_sha16": src_hash,
         "launches_per_step": launches_per_render,
         "avg_launch_ms": round(avg_launch_s * 1e3, 4),

@@ -30,7 +30,7 @@ def collect(dirglob, kernel):
     seen = collections.defaultdict(set)
     for f in glob.glob(os.path.join(O, dirglob, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if kernel in r["Kernel_Name"]:
+            if any(k in r["Kernel_Name"] for k in ((kernel,) if isinstance(kernel, str) else kernel)):
                 agg[r["Counter_Name"]] += float(r["Counter_Value"])
                 if r["Dispatch_Id"] not in seen[r["Counter_Name"]]:
                     seen[r["Counter_Name"]].add(r["Dispatch_Id"])
@@ -39,12 +39,14 @@ def collect(dirglob, kernel):
 
 
 # ---- HBM traffic of wf_extend (full-SPP passes of the default command: same launch structure as the bench)
-agg, dur, n = collect(f"{tag}_pmc_*_SIZE_{wl}", "wf_extend<false>")
+# both closest-hit kernels: wf_extend<false> (bounces >= 1, and bounce 0 when packets do not pay) and wf_extend_packet<false> (primary
+# rays), i.e. the launches bench.py times as "the dominant kernel" (one HIP-event pair per closest-hit launch)
+agg, dur, n = collect(f"{tag}_pmc_*_SIZE_{wl}", ("wf_extend<false>", "wf_extend_packet<false>"))
 if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
     fetch = agg["FETCH_SIZE"] / n["FETCH_SIZE"]
     write = agg["WRITE_SIZE"] / n["WRITE_SIZE"]
     out = {
-        "workload": f"{workload} spp={W['spp_per_gpu']}", "kernel": "wf_extend<false>", "kernel_src_sha16": sha, "launches": n["FETCH_SIZE"],
+        "workload": f"{workload} spp={W['spp_per_gpu']}", "kernel": "wf_extend<false> + wf_extend_packet<false> (every closest-hit launch)", "kernel_src_sha16": sha, "launches": n["FETCH_SIZE"],
         # MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 64 B per L2 read request although a request moves a 128-B line ->
         # doubled, as the guide prescribes. The guide also says "other access widths are uncalibrated: calibrate on a known
         # byte count in your own access pattern": tools/ubench/gather64.hip (profiles/r02_gather64_calibration.txt) shows
@@ -57,7 +59,7 @@ if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
         "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
         "avg_launch_ms_under_pmc": dur["FETCH_SIZE"] / n["FETCH_SIZE"],
         "correction": "gfx950: FETCH_SIZE reports 64 B per 128-B read request -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; x1024 (KB)",
-        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over python3 bench.py {'--workload ' + wl if wl != 'sponza' else ''} --no-cpu-baseline --steps 1 --warmup 0, averaged over the wf_extend<false> dispatches",
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over python3 bench.py (one warm-up render first: the packet policy has settled) {'--workload ' + wl if wl != 'sponza' else ''} --no-cpu-baseline --steps 1 --warmup 0, averaged over the wf_extend<false> and wf_extend_packet<false> dispatches",
     }
     json.dump(out, open(os.path.join(O, f"{tag}_hbm_traffic_{wl}.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
@@ -65,7 +67,7 @@ else:
     print("no FETCH_SIZE/WRITE_SIZE data", dict(agg))
 
 # ---- SQ / TCP / TCC counters
-for kern, short in (("wf_extend<false>", "wf_extend"), ("wf_shade<false", "wf_shade")):
+for kern, short in (("wf_extend<false>", "wf_extend"), ("wf_extend_packet<false>", "wf_extend_packet"), ("wf_shade<false", "wf_shade")):
     agg, dur, n = collect(f"{tag}_pmc_sq*_{wl}", kern)
     if not agg:
         print("no SQ data for", kern)

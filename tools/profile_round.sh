@@ -13,7 +13,7 @@ python3 $R/bench.py $extra > $O/${tag}_bench_$wl.json 2> $O/${tag}_bench_$wl.err
 cd /tmp
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats_$wl -- python3 $R/bench.py $extra --no-cpu-baseline > $O/${tag}_stats_$wl.log 2>&1; echo "stats pass exit $?"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d $O/${tag}_pmc_${c}_$wl --pmc $c -- python3 $R/bench.py $extra --no-cpu-baseline --steps 1 --warmup 0 > $O/${tag}_pmc_${c}_$wl.log 2>&1; echo "$c pass exit $?"
+  timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d $O/${tag}_pmc_${c}_$wl --pmc $c -- python3 $R/bench.py $extra --no-cpu-baseline --steps 1 --warmup 1 > $O/${tag}_pmc_${c}_$wl.log 2>&1; echo "$c pass exit $?"
 done
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY" \
