@@ -56,6 +56,29 @@ def test_struct_layouts_match_the_c_headers(rt, tmp_path):
     assert got == want
 
 
+def test_sub_queue_regions_tile_the_queue(tmp_path):
+    """wf_shade's 64 output sub-queues (rt_device_types.h, wf_stripe_base): for any number of wave slots the regions are
+    disjoint, in order, each exactly as large as the slots dealt to it round-robin (so a region can never overflow), and
+    together they cover [0, 64 * slots)."""
+    import subprocess
+
+    src = tmp_path / "stripes.cpp"
+    src.write_text(
+        '#include <cstdio>\n#include "rt_device_types.h"\n'
+        "int main(){ const unsigned K = WF_STRIPES; unsigned long long bad = 0;\n"
+        " const unsigned cases[] = {0,1,2,63,64,65,127,128,129,1000,4095,4096,4097,65535,1000003,1048576};\n"
+        " for (unsigned n : cases) { unsigned expect = 0;\n"
+        "  for (unsigned k = 0; k < K; ++k) { const unsigned slots_k = n / K + (k < n % K ? 1u : 0u);\n"
+        "   if (wf_stripe_base(k, n) != expect) ++bad; expect += 64u * slots_k; }\n"
+        "  if (expect != 64u * n) ++bad; }\n"
+        ' printf("%llu %u %u\\n", bad, (unsigned)WF_STRIPES, (unsigned)WF_STRIPE_BUF_WORDS); return 0; }\n'
+    )
+    exe = tmp_path / "stripes"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "raytracing-course-hw-public_amd", "csrc"), str(src), "-o", str(exe)])
+    bad, k, words = (int(x) for x in subprocess.check_output([str(exe)]).split())
+    assert bad == 0 and k == 64 and words == 64 * 32 + 65
+
+
 def test_no_gpu_fails_loudly(rt, sg):
     """The product never falls back to a CPU path: without a HIP device rt_create reports RT_ERR_NO_DEVICE."""
     if rt.device_count() > 0:
