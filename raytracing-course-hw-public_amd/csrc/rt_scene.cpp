@@ -47,6 +47,10 @@ template <class T> int upload(const std::vector<T> &v, const T **out, std::vecto
     return RT_OK;
 }
 
+// wf_advance scans the sub-queue fill levels with ONE wave (a lane per sub-queue) and wf_sort_keys finds a ray's sub-queue with
+// a power-of-two binary search (rt_wavefront.hip)
+static_assert(WF_STRIPES == 64u && (WF_STRIPES & (WF_STRIPES - 1u)) == 0u, "WF_STRIPES must equal the wave size (64)");
+
 // device allocation that is released on every return path of the probe entry points
 struct DevBuf {
     void *p = nullptr;
