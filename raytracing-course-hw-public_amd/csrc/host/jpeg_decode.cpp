@@ -286,6 +286,8 @@ struct Decoder {
     void scan_header(const uint8_t *p, int len) {
         if (!seen_sof)
             bad("scan before the frame header");
+        if (len < 6) // Ns + one component + Ss, Se, Ah/Al: anything shorter would read past the segment (and the file)
+            bad("bad SOS");
         scan_n = p[0];
         if (scan_n < 1 || scan_n > ncomp || len != 4 + 2 * scan_n)
             bad("bad SOS");

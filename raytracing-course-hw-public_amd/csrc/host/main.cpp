@@ -38,7 +38,13 @@ int main(int argc, char **argv) {
     const char *dev_env = std::getenv("RT_DEVICE");
     rt_scene *scene = nullptr;
     const int device = dev_env ? std::atoi(dev_env) : (rt_device_count() > 1 ? RT_ALL_DEVICES : 0);
-    if (rt_create(rt_loaded_desc(loaded), device, &scene) != RT_OK) {
+    int crc = rt_create(rt_loaded_desc(loaded), device, &scene);
+    if (crc == RT_ERR_COMM && device == RT_ALL_DEVICES) {
+        // the multi-GPU group could not be formed (librccl missing, or it refuses this device set): one GPU still renders
+        std::cerr << "rt_create: " << rt_last_error() << "; falling back to GPU 0 (set RT_DEVICE to choose another)" << std::endl;
+        crc = rt_create(rt_loaded_desc(loaded), 0, &scene);
+    }
+    if (crc != RT_OK) {
         rt_loaded_free(loaded);
         return die("rt_create");
     }

@@ -173,17 +173,21 @@ void load_txt(const std::string &path, rt_loaded_scene &res) {
                 throw TxtError{"line " + std::to_string(line) + ": " + cmd + " outside NEW_PRIMITIVE"};
             return cur;
         };
+        // DIMENSIONS / SAMPLES / RAY_DEPTH are counts: finite, non-negative, integral and small enough to be exact in a float
+        auto as_count = [&](float v, float hi) -> uint32_t {
+            if (!(v >= 0.0f && v <= hi) || v != std::floor(v))
+                throw TxtError{"line " + std::to_string(line) + ": " + cmd + " out of range (an integer in 0.." + std::to_string((long long)hi) + ")"};
+            return (uint32_t)v;
+        };
         if (cmd == "DIMENSIONS") {
             read_floats(ls, f, 2, cmd, line);
-            res.file_width = (uint32_t)f[0], res.file_height = (uint32_t)f[1];
+            res.file_width = as_count(f[0], 16777216.0f), res.file_height = as_count(f[1], 16777216.0f);
         } else if (cmd == "RAY_DEPTH") {
             read_floats(ls, f, 1, cmd, line);
-            if (!(f[0] >= 0 && f[0] <= 32))
-                throw TxtError{"line " + std::to_string(line) + ": RAY_DEPTH out of range (0..32)"};
-            ray_depth = (uint32_t)f[0];
+            ray_depth = as_count(f[0], 32.0f);
         } else if (cmd == "SAMPLES") {
             read_floats(ls, f, 1, cmd, line);
-            res.file_samples = (uint32_t)f[0];
+            res.file_samples = as_count(f[0], 16777216.0f);
         } else if (cmd == "BG_COLOR") {
             read_floats(ls, bg, 3, cmd, line);
         } else if (cmd == "CAMERA_POSITION") {

@@ -284,3 +284,32 @@ def test_png_decoder_rejects_malformed_headers(rt, tmp_path):
         with pytest.raises(rt.RtError) as e:
             rt.png_decode(str(p))
         assert e.value.code == 6, name  # RT_ERR_FORMAT
+
+
+# ------------------------------------------------------------------------------------------------ INTEGRATION.md binding
+REFERENCE_SRC = "/root/reference/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_SRC), reason="needs the reference headers (absent on the GPU box)")
+def test_integration_binding_compiles_against_the_reference(tmp_path):
+    """The C++ binding INTEGRATION.md tells a maintainer to add (run_raytracer_amd in place of run_raytracer,
+    src/main.cpp:37) must keep compiling against the reference's own headers (scene.h:74-90, geometry.h:633-643,
+    image.h:14-83) and include/rt_abi.h: every ```cpp block of the file is extracted and syntax-checked, the two
+    statement-level snippets inside a function body."""
+    import subprocess
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```cpp\n(.*?)```", text, flags=re.S)
+    binding = [b for b in blocks if "run_raytracer_amd" in b and "#include" in b]
+    assert len(binding) == 1, "INTEGRATION.md must hold exactly one complete binding block"
+    src = tmp_path / "binding_check.cpp"
+    parts = ["#include <cmath>\n#include <vector>\n", binding[0]]
+    # the rgb8 variant: statements that live inside run_raytracer_amd, after `dev` and `p` exist
+    rgb8 = [b for b in blocks if "rt_render_rgb8" in b and "#include" not in b]
+    assert rgb8, "the device-film snippet is gone from INTEGRATION.md"
+    parts.append("inline void rgb8_variant(rt_scene *dev, rt_params p, Image &image) {\n" + rgb8[0] + "    (void)rc;\n}\n")
+    parts.append("int main() { Scene s; Image img(4, 4, {1, 1, 1}); run_raytracer_amd(s, img); return 0; }\n")
+    src.write_text("".join(parts))
+    r = subprocess.run(["g++", "-std=c++20", "-fsyntax-only", "-I", REFERENCE_SRC, "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

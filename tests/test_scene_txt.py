@@ -55,6 +55,10 @@ def test_grammar_and_material_mapping(rt):
     ("NEW_PRIMITIVE\nELLIPSOID 1 1\n", "expects 3 numbers"),
     ("NEW_PRIMITIVE\nCOLOR 1 1 1\nNEW_PRIMITIVE\nBOX 1 1 1\n", "without ELLIPSOID"),
     ("RAY_DEPTH 99\n", "RAY_DEPTH out of range"),
+    ("RAY_DEPTH 2.7\n", "RAY_DEPTH out of range"),
+    ("SAMPLES -4\n", "SAMPLES out of range"),
+    ("SAMPLES nan\n", "SAMPLES out of range"),
+    ("DIMENSIONS 640 1e30\n", "DIMENSIONS out of range"),
     ("\n\n", "empty scene file"),
 ])
 def test_errors_are_codes_with_line_numbers(rt, tmp_path, text, needle):
