@@ -155,8 +155,11 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--bvh", default="reference", choices=["reference", "device"],
                     help="reference: host build in the reference's exact topology (parity mode, the headline); device: LBVH built on the GPU (production mode: same closest hits, other topology)")
+    ap.add_argument("--traversal", default="reference", choices=["reference", "global"],
+                    help="reference: the reference's traversal order and pruning (parity mode, the headline); global: prune against the global best hit (production: fewer node visits, same hits)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
+    gbest = args.traversal == "global"
 
     import numpy as np  # noqa: F401
     import torch  # imported BEFORE the HIP library so that one HIP runtime serves both (same soname)
@@ -187,7 +190,7 @@ def main() -> None:
     tex_size = args.tex_size or wl["tex_size"]
     n_pix = W * H
     full_size = (W, H, n_tri, tex_size) == (wl["width"], wl["height"], wl["triangles"], wl["tex_size"]) and spp == wl["spp_per_gpu"] * world
-    workload_id = (args.workload if full_size else f"{args.workload}-custom") + ("" if args.bvh == "reference" else "-lbvh")
+    workload_id = (args.workload if full_size else f"{args.workload}-custom") + ("" if args.bvh == "reference" else "-lbvh") + ("-gbest" if gbest else "")
 
     t0 = time.time()
     scene = rt.scenegen.room_scene(n_tri, seed=SEED, tex_size=tex_size, n_tex_sets=16, n_materials=64, n_lights=16,
@@ -210,9 +213,9 @@ def main() -> None:
 
     def step():
         if film:
-            _, st = dev.run_raytracer_rgb8(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_rgb8=img.data_ptr())
+            _, st = dev.run_raytracer_rgb8(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_rgb8=img.data_ptr(), global_best=gbest)
         else:
-            _, st = dev.run_raytracer(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr())
+            _, st = dev.run_raytracer(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr(), global_best=gbest)
         # N > 1: RCCL gather of this rank's interleaved blocks to rank 0 over xGMI (no-op at N = 1)
         gather.gather(img if args.backend == "nccl" else img.cpu())
         return st
@@ -248,7 +251,7 @@ def main() -> None:
     # triangle tests x 36); one render = `dominant_launches` launches (passes x bounces). Counters are per-sample event
     # counts; they are collected on a bounded budget (<= 64 M samples) and scaled to the step's sample count.
     cnt_spp = max(1, min(spp, (64 << 20) // max(1, my_pixels)))
-    _, cst = dev.run_raytracer(W, H, cnt_spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr(), counters=True)
+    _, cst = dev.run_raytracer(W, H, cnt_spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr(), counters=True, global_best=gbest)
     scale = spp / cnt_spp
     all_bytes = algorithmic_bytes(cst, 0) * scale + 12.0 * my_pixels
     trav_bytes = float(cst["box_tests"] * 24 + cst["nodes_visited"] * 16 + cst["tri_tests"] * 36) * scale
@@ -360,6 +363,7 @@ def main() -> None:
                 "triangles": int(scene.n_triangles),
                 "sharding": f"interleaved {SHARD_ROWS}-row tiles over {world} GPU(s), RCCL gather of the {'rgb8 image' if film else 'float3 framebuffer'}" if world > 1 else "single GPU",
                 "film": "device (rt_render_rgb8)" if film else "none (linear float3)",
+                "traversal": "global-best pruning (production)" if gbest else "reference order and pruning (parity mode)",
                 "bvh": "reference topology, host build (parity mode)" if args.bvh == "reference" else "LBVH built on the device (production mode: identical closest hits, different topology and counters)",
             },
             "roofline": roofline,

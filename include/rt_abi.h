@@ -163,9 +163,15 @@ enum {
                               library's stream is not ordered with any caller stream. */
     RT_FLAG_COUNTERS = 2,  /* run the instrumented kernel variant and fill the event counters of rt_stats
                               (slower; timing fields are filled whenever `stats` is non-NULL) */
-    RT_FLAG_MEGAKERNEL = 4 /* RT_RNG_DEVICE only: use the persistent one-lane-per-pixel megakernel instead of the
+    RT_FLAG_MEGAKERNEL = 4, /* RT_RNG_DEVICE only: use the persistent one-lane-per-pixel megakernel instead of the
                               wavefront pipeline (same image bit for bit; kept as a cross-check. RT_RNG_REFERENCE
                               always uses the megakernel: its RNG stream is sequential per 256-pixel span) */
+    RT_FLAG_GLOBAL_BEST = 8 /* production traversal (wavefront pipeline only): BVH::intersect_ray prunes a far child only
+                              against the NEAR subtree's local best (bvh.h:216-223); with this flag every box is culled
+                              against the GLOBAL best hit so far, which visits a subset of the reference's nodes. The
+                              closest hit is the same (t bit for bit) except where a triangle's t rounds below its own
+                              box's entry distance, or on exact ties; the event counters differ. Off by default: the
+                              parity mode reproduces the reference's order and counters. Environment: RT_TRAVERSAL=global. */
 };
 
 /* Per-render statistics (optional out-parameter). Counters are layout independent event counts in the
@@ -225,6 +231,18 @@ int rt_render(rt_scene *scene, const rt_params *params, float *fb_rgb, rt_stats 
  * analytic primitive i; 0xFFFFFFFF for a miss), and bct[3] = (b, c, t) of bvh.h:83-85 ((0, 0, t) for an analytic
  * primitive). Used by the parity tests for bit-exact hit indices. */
 int rt_cast_rays(rt_scene *scene, const float *rays, uint32_t n, uint32_t *prim_out, float *bct_out);
+
+/* The same probe through the RENDERER's closest-hit kernels (the wavefront pipeline's wf_extend / wf_extend_packet over a
+ * queue made of `rays`), so that tests exercise the production kernels on arbitrary rays. mode: RT_CAST_*. `stats` (optional)
+ * receives the event counters of the launch (casts, nodes_visited, box_tests, tri_tests) and its device time. */
+enum {
+    RT_CAST_PROBE = 0,         /* = rt_cast_rays: one lane per ray, the reference's recursion as an explicit stack */
+    RT_CAST_EXTEND = 1,        /* wf_extend, reference traversal order (parity mode) */
+    RT_CAST_EXTEND_GLOBAL = 2, /* wf_extend, global-best pruning (RT_FLAG_GLOBAL_BEST) */
+    RT_CAST_PACKET = 3,        /* wf_extend_packet (64 consecutive rays = one packet), reference order */
+    RT_CAST_PACKET_GLOBAL = 4  /* wf_extend_packet, global-best pruning */
+};
+int rt_cast_rays_ex(rt_scene *scene, const float *rays, uint32_t n, uint32_t mode, uint32_t *prim_out, float *bct_out, rt_stats *stats);
 
 /* Light-pdf probe: bvh_mix_dist::pdf (raytracer.h:363-375) for n (origin, dir) pairs. */
 int rt_light_pdf(rt_scene *scene, const float *rays, uint32_t n, float *pdf_out);

@@ -25,6 +25,12 @@ from ._ctypes_abi import (
     RT_FLAG_DEVICE_FB,
     RT_BUILD_DEVICE_LBVH,
     RT_FLAG_MEGAKERNEL,
+    RT_FLAG_GLOBAL_BEST,
+    RT_CAST_PROBE,
+    RT_CAST_EXTEND,
+    RT_CAST_EXTEND_GLOBAL,
+    RT_CAST_PACKET,
+    RT_CAST_PACKET_GLOBAL,
     RT_OK,
     RT_RNG_DEVICE,
     RT_RNG_REFERENCE,
@@ -180,11 +186,13 @@ class DeviceScene:
         device_fb: int = 0,
         counters: bool = False,
         megakernel: bool = False,
+        global_best: bool = False,
     ):
         """run_raytracer(scene, image) (raytracer.h:629): returns (linear float framebuffer (H,W,3), stats dict).
         With `device_fb` (a device pointer) the framebuffer stays in HBM and None is returned for it.
         `counters=True` runs the instrumented kernel variant and fills the event counters of the stats."""
-        p = RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block, (RT_FLAG_COUNTERS if counters else 0) | (RT_FLAG_MEGAKERNEL if megakernel else 0))
+        p = RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block,
+                     (RT_FLAG_COUNTERS if counters else 0) | (RT_FLAG_MEGAKERNEL if megakernel else 0) | (RT_FLAG_GLOBAL_BEST if global_best else 0))
         st = RtStats()
         if device_fb:
             p.flags |= RT_FLAG_DEVICE_FB
@@ -207,10 +215,11 @@ class DeviceScene:
         out: Optional[np.ndarray] = None,
         device_rgb8: int = 0,
         rng_mode: int = RT_RNG_DEVICE,
+        global_best: bool = False,
     ):
         """run_raytracer(scene, image) with the reference's own output type (image.h:40-42): the tone-mapped rgb8 image,
         film applied on the device. Returns ((H,W,3) uint8 array or None with `device_rgb8`, stats dict)."""
-        p = RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block, 0)
+        p = RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block, RT_FLAG_GLOBAL_BEST if global_best else 0)
         st = RtStats()
         if device_rgb8:
             p.flags |= RT_FLAG_DEVICE_FB
@@ -235,6 +244,17 @@ class DeviceScene:
         bct = np.zeros((n, 3), dtype=np.float32)
         _check(lib().rt_cast_rays(self._h, fptr(rays), n, u32ptr(prim), fptr(bct)))
         return prim, bct
+
+    def cast_rays_ex(self, rays: np.ndarray, mode: int):
+        """rt_cast_rays_ex: the closest-hit probe through the renderer's own kernels (mode = RT_CAST_*).
+        Returns (prim, bct, stats dict with casts / nodes_visited / box_tests / tri_tests / kernel_ms)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        prim = np.zeros(n, dtype=np.uint32)
+        bct = np.zeros((n, 3), dtype=np.float32)
+        st = RtStats()
+        _check(lib().rt_cast_rays_ex(self._h, fptr(rays), n, int(mode), u32ptr(prim), fptr(bct), C.byref(st)))
+        return prim, bct, st.as_dict()
 
     def light_pdf(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)

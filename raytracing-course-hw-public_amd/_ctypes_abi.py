@@ -20,6 +20,8 @@ RT_RNG_REFERENCE = 1
 RT_FLAG_DEVICE_FB = 1
 RT_FLAG_COUNTERS = 2
 RT_FLAG_MEGAKERNEL = 4
+RT_FLAG_GLOBAL_BEST = 8
+RT_CAST_PROBE, RT_CAST_EXTEND, RT_CAST_EXTEND_GLOBAL, RT_CAST_PACKET, RT_CAST_PACKET_GLOBAL = range(5)
 
 RT_OK = 0
 ERROR_NAMES = {
@@ -144,6 +146,7 @@ ABI_PROTOTYPES = {
     "rt_destroy": (None, [C.c_void_p]),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(RtParams), C.c_void_p, C.POINTER(RtStats)]),
     "rt_cast_rays": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, c_u32_p, c_float_p]),
+    "rt_cast_rays_ex": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, C.c_uint32, c_u32_p, c_float_p, C.POINTER(RtStats)]),
     "rt_light_pdf": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, c_float_p]),
     "rt_bvh_info": (C.c_int, [C.c_void_p, C.c_int, c_u32_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
     "rt_tonemap_rgb8": (None, [c_float_p, C.c_size_t, c_u8_p]),

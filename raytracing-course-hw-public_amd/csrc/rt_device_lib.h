@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/rt_abi.h"
 #include "../../include/rt_devspec.h"
 #include "../../include/rt_primspec.h"
@@ -382,13 +384,16 @@ template <int LDS_DEPTH> struct StackMemT {
 // when the depth wanders further than LDS_DEPTH from where it was — with StackMemT's fixed split (positions >= LDS_DEPTH
 // always in scratch) every push and pop beyond depth 7 went to scratch: 1.2 scratch pushes per cast on S-sponza (0.65 with
 // the ring), 9x HBM write amplification of the kernel's real output, the hit records (profiles/r02_write_amp.txt).
-template <int LDS_DEPTH> struct RingStackT {
-    uint32_t *lds; // [3][LDS_DEPTH][256] dwords, this thread's column starts at lds + threadIdx.x
-    // Evicted frames go to a global workspace, one 16-byte record {ref, d_far, saved local best, -} per (position, thread),
-    // laid out [position][thread of the grid]: an eviction or a refill is ONE 16-byte access (the three per-lane scratch
+template <int LDS_DEPTH, int WORDS = 3> struct RingStackT {
+    // WORDS = 3: the reference traversal's frame {ref, d_far, saved local best}; WORDS = 2: the global-best traversal's {ref, d_far}
+    static_assert(WORDS == 2 || WORDS == 3, "a frame is {ref, d_far} or {ref, d_far, saved local best}");
+    using Rec = std::conditional_t<WORDS == 3, uint4, uint2>;
+    uint32_t *lds; // [WORDS][LDS_DEPTH][256] dwords, this thread's column starts at lds + threadIdx.x
+    // Evicted frames go to a global workspace, one record {ref, d_far[, saved local best, -]} per (position, thread),
+    // laid out [position][thread of the grid]: an eviction or a refill is ONE 16-byte (8-byte) access (the three per-lane scratch
     // arrays this replaces cost three 4-byte accesses in three different 256-byte rows, i.e. three 32-byte sector writes
     // once the lines left L2), and neighbouring lanes' records of one position share lines.
-    uint4 *ov;      // this thread's record of position 0
+    Rec *ov;        // this thread's record of position 0
     uint32_t stride; // records per position = threads of the grid
     int base;       // positions [base, newest] are in LDS
     DEV static uint32_t slot_of(uint32_t pos) { // pos % LDS_DEPTH for pos < 64
@@ -396,39 +401,53 @@ template <int LDS_DEPTH> struct RingStackT {
             return pos & 7u;
         else if constexpr (LDS_DEPTH == 4)
             return pos & 3u;
+        else if constexpr (LDS_DEPTH == 16)
+            return pos & 15u;
         else {
             // pos / LDS_DEPTH by a full-rate 24-bit multiply (a 32-bit v_mul_lo_u32, which the compiler picks for a plain
             // `*` here, issues at quarter rate), then pos - LDS_DEPTH * q with shifts and adds
             uint32_t q;
-            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(q) : "v"(pos), "v"((uint32_t)((256 + LDS_DEPTH - 1) / LDS_DEPTH)));
-            q >>= 8;
-            static_assert(LDS_DEPTH == 6 || LDS_DEPTH == 5 || LDS_DEPTH == 12 || LDS_DEPTH == 3 || LDS_DEPTH == 8 || LDS_DEPTH == 4, "add the shift/add form of LDS_DEPTH * q");
-            const uint32_t m = LDS_DEPTH == 6 ? (q << 2) + (q << 1) : LDS_DEPTH == 5 ? (q << 2) + q : LDS_DEPTH == 12 ? (q << 3) + (q << 2) : (q << 1) + q;
+            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(q) : "v"(pos), "v"((uint32_t)((65536 + LDS_DEPTH - 1) / LDS_DEPTH)));
+            q >>= 16;
+            static_assert(LDS_DEPTH == 6 || LDS_DEPTH == 5 || LDS_DEPTH == 12 || LDS_DEPTH == 3 || LDS_DEPTH == 9 || LDS_DEPTH == 10 || LDS_DEPTH == 7, "add the shift/add form of LDS_DEPTH * q");
+            const uint32_t m = LDS_DEPTH == 6    ? (q << 2) + (q << 1)
+                               : LDS_DEPTH == 5  ? (q << 2) + q
+                               : LDS_DEPTH == 12 ? (q << 3) + (q << 2)
+                               : LDS_DEPTH == 9  ? (q << 3) + q
+                               : LDS_DEPTH == 10 ? (q << 3) + (q << 1)
+                               : LDS_DEPTH == 7  ? (q << 3) - q
+                                                 : (q << 1) + q;
             return pos - m;
         }
     }
     DEV void reset() { base = 0; }
-    DEV void push(int pos, uint32_t ref, float d, float loc) {
+    DEV void push(int pos, uint32_t ref, float d, float loc = 0.0f) {
         const uint32_t slot = slot_of((uint32_t)pos);
         if (pos - base == LDS_DEPTH) { // ring full: the slot about to be overwritten holds position `base`, the oldest
             DIAG(28, (unsigned long long)__popcll(__ballot(1)));
-            ov[(size_t)base * stride] = make_uint4(lds[(0 * LDS_DEPTH + slot) * 256], lds[(1 * LDS_DEPTH + slot) * 256], lds[(2 * LDS_DEPTH + slot) * 256], 0u);
+            if constexpr (WORDS == 3)
+                ov[(size_t)base * stride] = make_uint4(lds[(0 * LDS_DEPTH + slot) * 256], lds[(1 * LDS_DEPTH + slot) * 256], lds[(2 * LDS_DEPTH + slot) * 256], 0u);
+            else
+                ov[(size_t)base * stride] = make_uint2(lds[(0 * LDS_DEPTH + slot) * 256], lds[(1 * LDS_DEPTH + slot) * 256]);
             ++base;
         }
         lds[(0 * LDS_DEPTH + slot) * 256] = ref;
         lds[(1 * LDS_DEPTH + slot) * 256] = __float_as_uint(d);
-        lds[(2 * LDS_DEPTH + slot) * 256] = __float_as_uint(loc);
+        if constexpr (WORDS == 3)
+            lds[(2 * LDS_DEPTH + slot) * 256] = __float_as_uint(loc);
     }
     DEV void pop(int pos, uint32_t &ref, float &d, float &loc) {
         const uint32_t slot = slot_of((uint32_t)pos);
         ref = lds[(0 * LDS_DEPTH + slot) * 256];
         d = __uint_as_float(lds[(1 * LDS_DEPTH + slot) * 256]);
-        loc = __uint_as_float(lds[(2 * LDS_DEPTH + slot) * 256]);
+        if constexpr (WORDS == 3)
+            loc = __uint_as_float(lds[(2 * LDS_DEPTH + slot) * 256]);
         if (pos < base) { // the ring is empty: take the frame back from the workspace
-            const uint4 v = ov[(size_t)pos * stride];
+            const Rec v = ov[(size_t)pos * stride];
             ref = v.x;
             d = __uint_as_float(v.y);
-            loc = __uint_as_float(v.z);
+            if constexpr (WORDS == 3)
+                loc = __uint_as_float(v.z);
             base = pos;
         }
     }
@@ -439,28 +458,35 @@ template <int LDS_DEPTH> struct RingStackT {
         const uint32_t slot = slot_of(p);
         ref = lds[(0 * LDS_DEPTH + slot) * 256];
         d = __uint_as_float(lds[(1 * LDS_DEPTH + slot) * 256]);
-        loc = __uint_as_float(lds[(2 * LDS_DEPTH + slot) * 256]);
+        if constexpr (WORDS == 3)
+            loc = __uint_as_float(lds[(2 * LDS_DEPTH + slot) * 256]);
         // keep the LDS reads where they are: sunk into the branch below they would merge with the global loads into
         // generic flat_loads of a selected pointer
-        asm volatile("" : "+v"(ref), "+v"(d), "+v"(loc));
+        if constexpr (WORDS == 3)
+            asm volatile("" : "+v"(ref), "+v"(d), "+v"(loc));
+        else
+            asm volatile("" : "+v"(ref), "+v"(d));
         if (want && pos < base) {
-            const uint4 v = ov[(size_t)pos * stride];
+            const Rec v = ov[(size_t)pos * stride];
             ref = v.x;
             d = __uint_as_float(v.y);
-            loc = __uint_as_float(v.z);
+            if constexpr (WORDS == 3)
+                loc = __uint_as_float(v.z);
             base = pos;
         }
     }
 };
-#define RT_DECLARE_RING_STACK(NAME, DEPTH, SHARED_ARRAY, OVERFLOW, STRIDE)     \
-    RingStackT<(DEPTH)> NAME;                                                  \
-    NAME.lds = (SHARED_ARRAY) + threadIdx.x;                                   \
-    NAME.ov = (OVERFLOW) + ((size_t)blockIdx.x * blockDim.x + threadIdx.x);    \
-    NAME.stride = (STRIDE);                                                    \
+#define RT_DECLARE_RING_STACK_W(NAME, DEPTH, WORDS, SHARED_ARRAY, OVERFLOW, STRIDE)                                                    \
+    RingStackT<(DEPTH), (WORDS)> NAME;                                                                                            \
+    NAME.lds = (SHARED_ARRAY) + threadIdx.x;                                                                                      \
+    NAME.ov = reinterpret_cast<RingStackT<(DEPTH), (WORDS)>::Rec *>(OVERFLOW) + ((size_t)blockIdx.x * blockDim.x + threadIdx.x); \
+    NAME.stride = (STRIDE);                                                                                                       \
     NAME.base = 0
+#define RT_DECLARE_RING_STACK(NAME, DEPTH, SHARED_ARRAY, OVERFLOW, STRIDE) RT_DECLARE_RING_STACK_W(NAME, DEPTH, 3, SHARED_ARRAY, OVERFLOW, STRIDE)
 
 #define STACK_LDS_DWORDS (3 * LDS_DEPTH * 256)
 #define STACK_LDS_DWORDS_FOR(depth) (3 * (depth) * 256)
+#define STACK_LDS_DWORDS_W(depth, words) ((words) * (depth) * 256)
 #define RT_DECLARE_STACK(NAME, DEPTH, SHARED_ARRAY)          \
     uint32_t NAME##_ov_ref[RT_MAX_STACK - (DEPTH)];         \
     float NAME##_ov_d[RT_MAX_STACK - (DEPTH)];              \
@@ -506,14 +532,21 @@ DEV bool ray_fast_ok_ray(V3 o, V3 d) {
     return (d.x == d.x) & (d.y == d.y) & (d.z == d.z) & (lo >= RANGE_LO) & (hi <= RANGE_HI) & coord_in_fast_range(o.x) & coord_in_fast_range(o.y) &
            coord_in_fast_range(o.z);
 }
-DEV void trav_init_stored(Trav &T, const DevBvh &bvh, V3 o, V3 d, V3 r, bool ray_ok) {
+// GB (production traversal, RT_FLAG_GLOBAL_BEST): T.t_loc is the GLOBAL best t so far (+inf before the first hit) and every
+// box is culled against it: a child is visited iff !(best.t <= its entry distance). The reference prunes a far child only
+// against the near subtree's local best (bvh.h:216-223), so the global rule visits a SUBSET of the reference's nodes and
+// returns the same hit unless a triangle's t rounds below its own box's entry distance — measured per scene by
+// tests/test_gpu_production.py. Frames shrink to {ref, d_far}: no saved local best.
+template <bool GB = false> DEV void trav_init_stored(Trav &T, const DevBvh &bvh, V3 o, V3 d, V3 r, bool ray_ok) {
     T.o = o;
     T.d = d;
     T.r = r;
     T.fast = ray_ok & (bvh.fast_ok != 0u);
     T.cur = (bvh.root == RT_NONE || bvh.n_tris == 0) ? T_DONE : bvh.root;
     T.sp = 0;
-    T.t_loc = RT_NAN;
+    T.t_loc = GB ? RT_INF : RT_NAN;
+    if constexpr (GB)
+        T.top_loc = 0.0f; // unused by the global-best frames
     T.best = Hit{RT_NONE, 0.f, 0.f, 0.f};
 }
 DEV void trav_init(Trav &T, const DevBvh &bvh, V3 o, V3 d) {
@@ -552,7 +585,7 @@ template <class STK> DEV void trav_pop(Trav &T, STK &stk) {
 
 // One record: an inner node (two child boxes) or one triangle of a big leaf. Leaves T.cur == T_POP when the lane has to
 // unwind; the caller chooses how (trav_pop: per-lane loop; trav_pop_wave: all lanes of the wave together).
-template <bool STATS, class STK> DEV void trav_step_core(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
+template <bool STATS, bool GB = false, class STK> DEV void trav_step_core(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
     const bool leaf = (T.cur & RT_LEAF_FLAG) != 0;
     const float4 *p = leaf ? reinterpret_cast<const float4 *>(bvh.tris + (T.cur & RT_LEAF_BEGIN_MASK)) : reinterpret_cast<const float4 *>(bvh.nodes + T.cur);
     const float4 r0 = p[0], r1 = p[1], r2 = p[2];
@@ -575,6 +608,10 @@ template <bool STATS, class STK> DEV void trav_step_core(Trav &T, const DevBvh &
             hl = box_hit_exact(lmin, lmax, T.o, T.d, min_dst, dl);
             hr = box_hit_exact(rmn, rmx, T.o, T.d, min_dst, dr);
         }
+        if constexpr (GB) { // cull against the global best
+            hl = hl && dl < T.t_loc;
+            hr = hr && dr < T.t_loc;
+        }
         if (hl & hr) {
             uint32_t near = left, far = right;
             float dfar = dr;
@@ -587,9 +624,11 @@ template <bool STATS, class STK> DEV void trav_step_core(Trav &T, const DevBvh &
                 stk.push(T.sp - 1, T.top_ref, T.top_d, T.top_loc); // spill the previous top
             T.top_ref = far;
             T.top_d = dfar;
-            T.top_loc = T.t_loc;
+            if constexpr (!GB) {
+                T.top_loc = T.t_loc;
+                T.t_loc = RT_NAN;
+            }
             ++T.sp;
-            T.t_loc = RT_NAN;
             T.cur = near;
         } else if (hl) {
             T.cur = left;
@@ -620,7 +659,7 @@ template <bool STATS, class STK> DEV void trav_step_core(Trav &T, const DevBvh &
     }
 }
 template <bool STATS, class STK> DEV void trav_step(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
-    trav_step_core<STATS>(T, bvh, stk, min_dst, st);
+    trav_step_core<STATS, false>(T, bvh, stk, min_dst, st);
     trav_pop(T, stk);
 }
 
@@ -628,7 +667,7 @@ template <bool STATS, class STK> DEV void trav_step(Trav &T, const DevBvh &bvh, 
 // (selects instead of per-lane branches: no exec-mask nesting and no register copies at control-flow joins).
 //   trav_step_inner_fast : trav_step_core for lanes the caller knows to be on an inner node with T.fast
 //   trav_pop_wave        : trav_pop for every lane in T_POP at once; lanes leave the loop as a wave
-template <bool STATS, class STK> DEV void trav_step_inner_fast(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
+template <bool STATS, bool GB = false, class STK> DEV void trav_step_inner_fast(Trav &T, const DevBvh &bvh, STK &stk, float min_dst, LaneStats<STATS> &st) {
     const float4 *p = reinterpret_cast<const float4 *>(bvh.nodes + T.cur);
     const float4 r0 = p[0], r1 = p[1], r2 = p[2];
     const float2 r3 = *reinterpret_cast<const float2 *>(p + 3);
@@ -636,22 +675,28 @@ template <bool STATS, class STK> DEV void trav_step_inner_fast(Trav &T, const De
     st.box(2);
     const uint32_t left = __float_as_uint(r3.x), right = __float_as_uint(r3.y);
     float dl, dr;
-    const bool hl = box_hit_fast(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), T.o, T.d, T.r, min_dst, dl);
-    const bool hr = box_hit_fast(mk(r1.z, r1.w, r2.x), mk(r2.y, r2.z, r2.w), T.o, T.d, T.r, min_dst, dr);
+    bool hl = box_hit_fast(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), T.o, T.d, T.r, min_dst, dl);
+    bool hr = box_hit_fast(mk(r1.z, r1.w, r2.x), mk(r2.y, r2.z, r2.w), T.o, T.d, T.r, min_dst, dr);
+    if constexpr (GB) { // cull against the global best
+        hl &= dl < T.t_loc;
+        hr &= dr < T.t_loc;
+    }
     const bool both = hl & hr;
     const bool swap = dl > dr; // bvh.h:216 (ties keep left first)
     if (both & (T.sp > 0))
         stk.push(T.sp - 1, T.top_ref, T.top_d, T.top_loc); // spill the previous top
     T.top_ref = both ? (swap ? left : right) : T.top_ref;
     T.top_d = both ? (swap ? dl : dr) : T.top_d;
-    T.top_loc = both ? T.t_loc : T.top_loc;
+    if constexpr (!GB) {
+        T.top_loc = both ? T.t_loc : T.top_loc;
+        T.t_loc = both ? RT_NAN : T.t_loc;
+    }
     T.sp += both ? 1 : 0;
-    T.t_loc = both ? RT_NAN : T.t_loc;
     T.cur = both ? (swap ? right : left) : (hl ? left : (hr ? right : T_POP));
 }
 // The same node step on a record the caller already holds (wf_extend_packet: one scalar fetch serves every lane standing on
 // the node). Guarded rays (T.fast false) take the reference division; the bookkeeping is trav_step_inner_fast's.
-template <bool STATS, class STK>
+template <bool STATS, bool GB = false, class STK>
 DEV void trav_inner_apply(Trav &T, STK &stk, V3 lmin, V3 lmax, V3 rmn, V3 rmx, uint32_t left, uint32_t right, float min_dst, LaneStats<STATS> &st) {
     st.node();
     st.box(2);
@@ -664,15 +709,21 @@ DEV void trav_inner_apply(Trav &T, STK &stk, V3 lmin, V3 lmax, V3 rmn, V3 rmx, u
         hl = box_hit_exact(lmin, lmax, T.o, T.d, min_dst, dl);
         hr = box_hit_exact(rmn, rmx, T.o, T.d, min_dst, dr);
     }
+    if constexpr (GB) { // cull against the global best
+        hl = hl && dl < T.t_loc;
+        hr = hr && dr < T.t_loc;
+    }
     const bool both = hl & hr;
     const bool swap = dl > dr; // bvh.h:216 (ties keep left first)
     if (both & (T.sp > 0))
         stk.push(T.sp - 1, T.top_ref, T.top_d, T.top_loc); // spill the previous top
     T.top_ref = both ? (swap ? left : right) : T.top_ref;
     T.top_d = both ? (swap ? dl : dr) : T.top_d;
-    T.top_loc = both ? T.t_loc : T.top_loc;
+    if constexpr (!GB) {
+        T.top_loc = both ? T.t_loc : T.top_loc;
+        T.t_loc = both ? RT_NAN : T.t_loc;
+    }
     T.sp += both ? 1 : 0;
-    T.t_loc = both ? RT_NAN : T.t_loc;
     T.cur = both ? (swap ? right : left) : (hl ? left : (hr ? right : T_POP));
 }
 // Scalar (s_load) reads of scene constants at a wave-uniform address: the constant address space tells the compiler that
@@ -692,7 +743,7 @@ DEV uint32_t wave_min_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 // one unwind step for every lane in T_POP, as straight-line wave code (lanes in other states pass through unchanged)
-template <class STK> DEV void trav_pop_once(Trav &T, STK &stk) {
+template <bool GB = false, class STK> DEV void trav_pop_once(Trav &T, STK &stk) {
     DIAG(7, 1);
     DIAG(27, (unsigned long long)__popcll(__ballot(T.cur == T_POP)));
     const bool pop = T.cur == T_POP;
@@ -700,20 +751,23 @@ template <class STK> DEV void trav_pop_once(Trav &T, STK &stk) {
     const int nsp = T.sp - 1;
     const bool refill = go & (nsp > 0);
     uint32_t n_ref;
-    float n_d, n_loc;
+    float n_d, n_loc = 0.0f;
     stk.pop_masked(nsp - 1, refill, n_ref, n_d, n_loc);
     const float t_near = T.t_loc;
-    const bool visit = !(t_near <= T.top_d); // !has || t_near > d_far (bvh.h:221)
+    // reference: !has || t_near > d_far against the NEAR subtree's local best (bvh.h:221); GB: against the global best
+    const bool visit = !(t_near <= T.top_d);
     T.cur = pop ? (go ? (visit ? T.top_ref : T_POP) : T_DONE) : T.cur;
-    T.t_loc = go ? fminf(T.top_loc, t_near) : t_near;
+    if constexpr (!GB)
+        T.t_loc = go ? fminf(T.top_loc, t_near) : t_near;
     T.sp = go ? nsp : T.sp;
     T.top_ref = refill ? n_ref : T.top_ref;
     T.top_d = refill ? n_d : T.top_d;
-    T.top_loc = refill ? n_loc : T.top_loc;
+    if constexpr (!GB)
+        T.top_loc = refill ? n_loc : T.top_loc;
 }
-template <class STK> DEV void trav_pop_wave(Trav &T, STK &stk) {
+template <bool GB = false, class STK> DEV void trav_pop_wave(Trav &T, STK &stk) {
     while (__ballot(T.cur == T_POP) != 0ull)
-        trav_pop_once(T, stk);
+        trav_pop_once<GB>(T, stk);
 }
 // bvh_mix_dist::pdf (raytracer.h:363-375) = BVH::foreach_intersection (bvh.h:237-260) over the light BVH summing
 // triangle_dist::pdf_at (raytracer.h:255-261) in DFS order (node objects, left subtree, right subtree).

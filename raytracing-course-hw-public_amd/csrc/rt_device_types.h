@@ -196,6 +196,8 @@ struct WfLaunch {
     uint32_t use_packet;     // this pass's primary rays go through wf_extend_packet (rt_scene.cpp decides: RT_WF_PACKET, samples per
                              // pixel, and what the kernel's own census said on an earlier pass)
     unsigned long long *packet_census; // [2] device: trips, lanes served (summed over the launch's waves)
+    uint32_t global_best;    // 0: the reference's traversal order and pruning (parity mode); 1: prune against the global best
+                             // (RT_FLAG_GLOBAL_BEST, production traversal: a subset of the reference's node visits)
     uint32_t sort_mode;      // 0 off, 1 cell+octant, 2 coarse cell + direction code, 3 octant+cell, 4 cell+octant+sub-cone (default) (RT_WF_SORT)
     size_t sort_temp_bytes;
     DevStats *stats;         // may be null

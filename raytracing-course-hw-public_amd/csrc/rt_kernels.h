@@ -47,6 +47,10 @@ hipError_t launch_light_pdf(const DevScene &S, const float *rays, uint32_t n, fl
 // `packet_census_out` (optional, host, 2 words): trips and lanes served of this pass's wf_extend_packet launch (0, 0 if it did not run)
 hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int num_cus, bool first_pass, bool last_pass, hipStream_t stream,
                                  EventPool *extend_events, unsigned long long *packet_census_out);
+// closest-hit probe through the renderer's own kernels: `rays` (6 floats each, device) -> queue -> wf_extend (or wf_extend_packet)
+// -> prim / bct (device). `L` carries the workspace (paths_in, hits, counters, stack_overflow, stats) and the traversal mode.
+hipError_t launch_wavefront_cast(const DevScene &S, WfLaunch L, const float *rays, uint32_t n, bool packet, bool stats, uint32_t *prim, float *bct,
+                                 hipStream_t stream);
 // bytes of temporary storage rocPRIM's radix sort needs for `n` (key, slot) pairs
 size_t wavefront_sort_temp_bytes(size_t n);
 } // namespace rt

@@ -195,6 +195,28 @@ struct rt_scene {
         return RT_OK;
     }
 
+    // the workspace half of a WfLaunch (after ensure_wavefront): queues, hit records, counters, stack workspace, sort buffers
+    void wf_bind(WfLaunch &W) {
+        W.paths_in = wf_paths[0];
+        W.paths_out = wf_paths[1];
+        W.hits = wf_hits;
+        W.fold = wf_fold;
+        W.sample_out = wf_samples;
+        W.accum = wf_accum;
+        W.counters = wf_counters;
+        W.stripes = wf_stripes;
+        W.stack_overflow = wf_stack_overflow;
+        W.stack_stride = wf_stack_stride;
+        W.diag = wf_counters + 64; // dev census words live behind the queue counters
+        for (int k = 0; k < 2; ++k) { // sort_vals[1] also carries the unsorted order (RT_WF_SORT=0: sort_mode 0)
+            W.sort_keys[k] = wf_sort_keys[k];
+            W.sort_vals[k] = wf_sort_vals[k];
+        }
+        W.sort_temp = wf_sort_temp;
+        W.sort_temp_bytes = wf_sort_temp_bytes;
+        W.packet_census = reinterpret_cast<unsigned long long *>(wf_counters + 32);
+    }
+
     ~rt_scene() {
         if (group) {
             rt::group_destroy(group);
@@ -720,35 +742,21 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
         W.seed = p->seed;
         W.tan_x = L.tan_x;
         W.tan_y = L.tan_y;
-        W.paths_in = s->wf_paths[0];
-        W.paths_out = s->wf_paths[1];
-        W.hits = s->wf_hits;
-        W.fold = s->wf_fold;
-        W.sample_out = s->wf_samples;
-        W.accum = s->wf_accum;
+        s->wf_bind(W);
         W.fb = d_fb;
-        W.counters = s->wf_counters;
-        W.stripes = s->wf_stripes;
-        W.stack_overflow = s->wf_stack_overflow;
-        W.stack_stride = s->wf_stack_stride;
-        W.diag = s->wf_counters + 64; // dev census words live behind the queue counters
         const char *sort_env = std::getenv("RT_WF_SORT");
-        for (int k = 0; k < 2; ++k) { // sort_vals[1] also carries the unsorted order (RT_WF_SORT=0: sort_mode 0)
-            W.sort_keys[k] = s->wf_sort_keys[k];
-            W.sort_vals[k] = s->wf_sort_vals[k];
-        }
         if (!s->wf_host_count && hipHostMalloc((void **)&s->wf_host_count, 8 * sizeof(uint32_t)) != hipSuccess)
             s->wf_host_count = nullptr;
         W.host_count = s->wf_host_count;
-        W.sort_temp = s->wf_sort_temp;
         W.sort_mode = sort_env ? (uint32_t)std::atoi(sort_env) : 4u; // 24-bit key: cell, octant, direction sub-cone (measured best)
-        W.sort_temp_bytes = s->wf_sort_temp_bytes;
+        // production traversal: global-best pruning (rt_abi.h RT_FLAG_GLOBAL_BEST; RT_TRAVERSAL=global for callers without flags)
+        const char *trav_env = std::getenv("RT_TRAVERSAL");
+        W.global_best = ((p->flags & RT_FLAG_GLOBAL_BEST) || (trav_env && !std::strcmp(trav_env, "global"))) ? 1u : 0u;
         // primary rays as packets (wf_extend_packet): RT_WF_PACKET=0 never, =1 always; default: from 16 samples per pixel and pass
         // up, until the kernel's census says its packets fall apart (fewer than 33 of 64 lanes served per trip: the measured
         // break-even against wf_extend, profiles/r02_packet.txt) for this image size / samples per pass
         const char *pkt_env = std::getenv("RT_WF_PACKET");
         const int pkt_mode = pkt_env ? std::atoi(pkt_env) : -1;
-        W.packet_census = reinterpret_cast<unsigned long long *>(s->wf_counters + 32);
         W.stats = L.stats;
         for (uint64_t p0 = 0; p0 < local_pixels; p0 += tile_pixels) {
             W.first_pixel = (uint32_t)p0;
@@ -891,6 +899,66 @@ extern "C" int rt_cast_rays(rt_scene *s, const float *rays, uint32_t n, uint32_t
     if (e != hipSuccess)
         rc = rt::fail(RT_ERR_HIP, std::string("rt_cast_rays: ") + hipGetErrorString(e));
     return rc;
+}
+
+extern "C" int rt_cast_rays_ex(rt_scene *s, const float *rays, uint32_t n, uint32_t mode, uint32_t *prim_out, float *bct_out, rt_stats *stats) {
+    if (s && s->group)
+        return rt_cast_rays_ex(rt::group_primary(s->group), rays, n, mode, prim_out, bct_out, stats);
+    if (mode == RT_CAST_PROBE) {
+        if (stats)
+            std::memset(stats, 0, sizeof(*stats));
+        return rt_cast_rays(s, rays, n, prim_out, bct_out);
+    }
+    if (!s || (n && (!rays || !prim_out || !bct_out)) || mode > RT_CAST_PACKET_GLOBAL)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_cast_rays_ex: bad argument");
+    if (stats)
+        std::memset(stats, 0, sizeof(*stats));
+    if (n == 0)
+        return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    if (int rc = s->ensure_wavefront(n, 1, 1); rc != RT_OK)
+        return rc;
+    DevBuf b_rays, b_bct, b_prim;
+    HIP_TRY(b_rays.alloc((size_t)n * 24));
+    HIP_TRY(b_bct.alloc((size_t)n * 12));
+    HIP_TRY(b_prim.alloc((size_t)n * 4));
+    WfLaunch W{};
+    s->wf_bind(W);
+    W.ray_depth = 1;
+    W.global_best = (mode == RT_CAST_EXTEND_GLOBAL || mode == RT_CAST_PACKET_GLOBAL) ? 1u : 0u;
+    W.stats = stats ? s->d_stats : nullptr;
+    const bool packet = mode == RT_CAST_PACKET || mode == RT_CAST_PACKET_GLOBAL;
+    hipError_t e = hipMemcpyAsync(b_rays.p, rays, (size_t)n * 24, hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess && stats)
+        e = hipMemsetAsync(s->d_stats, 0, sizeof(DevStats), s->stream);
+    if (e == hipSuccess)
+        e = hipEventRecord(s->ev0, s->stream);
+    if (e == hipSuccess)
+        e = rt::launch_wavefront_cast(s->dev, W, b_rays.as<float>(), n, packet, stats != nullptr, b_prim.as<uint32_t>(), b_bct.as<float>(), s->stream);
+    if (e == hipSuccess)
+        e = hipEventRecord(s->ev1, s->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(prim_out, b_prim.p, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(bct_out, b_bct.p, (size_t)n * 12, hipMemcpyDeviceToHost, s->stream);
+    DevStats h{};
+    if (e == hipSuccess && stats)
+        e = hipMemcpyAsync(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost, s->stream);
+    const hipError_t se = hipStreamSynchronize(s->stream); // also on failure: nothing may stay in flight over the DevBufs
+    if (e == hipSuccess)
+        e = se;
+    if (e != hipSuccess)
+        return rt::fail(RT_ERR_HIP, std::string("rt_cast_rays_ex: ") + hipGetErrorString(e));
+    if (stats) {
+        stats->casts = n;
+        stats->nodes_visited = h.nodes;
+        stats->box_tests = h.box_tests;
+        stats->tri_tests = h.tri_tests;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess)
+            stats->kernel_ms = ms;
+    }
+    return RT_OK;
 }
 
 extern "C" int rt_light_pdf(rt_scene *s, const float *rays, uint32_t n, float *pdf_out) {

@@ -38,7 +38,9 @@ namespace {
 #ifndef RT_EXT_LDS_DEPTH
 #define RT_EXT_LDS_DEPTH 6 /* LDS part of the traversal stack in wf_extend: 6 -> 26 KB/block -> 6 blocks (24 waves) per CU */
 #endif
-using ExtStack = RingStackT<RT_EXT_LDS_DEPTH>;
+#ifndef RT_EXT_GB_LDS_DEPTH
+#define RT_EXT_GB_LDS_DEPTH 9 /* global-best traversal: 8-byte frames {ref, d_far} -> 9 positions in the LDS the reference traversal's 6 x 12 B take */
+#endif
 #ifndef RT_SHADE_WAVES_PER_SIMD
 #define RT_SHADE_WAVES_PER_SIMD 4
 #endif
@@ -187,8 +189,9 @@ DEV void leaf_batch(Trav &T, const DevBvh &bvh, bool at_leaf, uint16_t *s_owner,
 #define RT_EXT_LEAF_MIN 20 /* run a leaf batch once this many lanes wait on a leaf */
 #endif
 
-template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) void wf_extend(const DevScene S, const WfLaunch L) {
-    __shared__ uint32_t s_stack[STACK_LDS_DWORDS_FOR(RT_EXT_LDS_DEPTH)];
+template <bool STATS, bool GB> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) void wf_extend(const DevScene S, const WfLaunch L) {
+    constexpr int DEPTH = GB ? RT_EXT_GB_LDS_DEPTH : RT_EXT_LDS_DEPTH, WORDS = GB ? 2 : 3;
+    __shared__ uint32_t s_stack[STACK_LDS_DWORDS_W(DEPTH, WORDS)];
     __shared__ uint16_t s_owner_all[4][64 * RT_LEAF_COOP_MAX + RT_LEAF_COOP_MAX]; // + overshoot of the unpredicated owner stores
     __shared__ unsigned long long s_min_all[4][64];
     __shared__ float2 s_bc_all[4][64];
@@ -197,7 +200,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
     unsigned long long *s_min = s_min_all[wave];
     float2 *s_bc = s_bc_all[wave];
     LaneStats<STATS> st;
-    RT_DECLARE_RING_STACK(stk, RT_EXT_LDS_DEPTH, s_stack, reinterpret_cast<uint4 *>(L.stack_overflow), L.stack_stride);
+    RT_DECLARE_RING_STACK_W(stk, DEPTH, WORDS, s_stack, L.stack_overflow, L.stack_stride);
 #ifdef RT_DIAG
     if (STATS && threadIdx.x == 0 && blockIdx.x == 0)
         g_diag = (DevStats *)L.diag;
@@ -247,7 +250,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
                 const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
                 const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
                 slot = jq; // the hit goes to the queue POSITION (see WfLaunch::hits)
-                trav_init_stored(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r2.x, r2.y, r2.z), __float_as_uint(r2.w) != 0u);
+                trav_init_stored<GB>(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r2.x, r2.y, r2.z), __float_as_uint(r2.w) != 0u);
                 stk.reset();
                 if (T.cur == T_DONE) // no geometry at all: immediate miss
                     *reinterpret_cast<float4 *>(L.hits + jq) = make_float4(__uint_as_float(RT_NONE), 0.f, 0.f, 0.f);
@@ -264,7 +267,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
         // (Tried and not kept: issuing the pop's LDS reads here and consuming them only behind the node fetch — 3 more live
         // VGPRs and the extra predicate traffic cost more than the hidden LDS round trip: 233.7 vs 238.5 Msamples/s.)
         const bool was_live = T.cur != T_DONE;
-        trav_pop_once(T, stk);
+        trav_pop_once<GB>(T, stk);
         if (was_live && T.cur == T_DONE)
             *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
         DG_STAMP(dg_pop);
@@ -302,15 +305,15 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
                 if (stepper) {
                     DIAG(18, 1);
                     DIAG_LANES(19);
-                    trav_step_inner_fast<STATS>(T, S.scene, stk, EPS, st);
+                    trav_step_inner_fast<STATS, GB>(T, S.scene, stk, EPS, st);
                 }
             } else if (stepper) {
-                trav_step_core<STATS>(T, S.scene, stk, EPS, st);
+                trav_step_core<STATS, GB>(T, S.scene, stk, EPS, st);
             }
             DG_STAMP(dg_node);
         }
 #if !RT_EXT_POP_ONCE
-        trav_pop_wave(T, stk); // unwind after a leaf batch or a node step, all lanes of the wave together
+        trav_pop_wave<GB>(T, stk); // unwind after a leaf batch or a node step, all lanes of the wave together
         DG_STAMP(dg_pop);
         if (active && T.cur == T_DONE)
             *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.t);
@@ -345,10 +348,11 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
 #ifndef RT_PKT_CHUNK
 #define RT_PKT_CHUNK 256u /* queue positions per ticket atomic (4 packets) */
 #endif
-template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) void wf_extend_packet(const DevScene S, const WfLaunch L) {
-    __shared__ uint32_t s_stack[STACK_LDS_DWORDS_FOR(RT_EXT_LDS_DEPTH)];
+template <bool STATS, bool GB> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) void wf_extend_packet(const DevScene S, const WfLaunch L) {
+    constexpr int DEPTH = GB ? RT_EXT_GB_LDS_DEPTH : RT_EXT_LDS_DEPTH, WORDS = GB ? 2 : 3;
+    __shared__ uint32_t s_stack[STACK_LDS_DWORDS_W(DEPTH, WORDS)];
     LaneStats<STATS> st;
-    RT_DECLARE_RING_STACK(stk, RT_EXT_LDS_DEPTH, s_stack, reinterpret_cast<uint4 *>(L.stack_overflow), L.stack_stride);
+    RT_DECLARE_RING_STACK_W(stk, DEPTH, WORDS, s_stack, L.stack_overflow, L.stack_stride);
     const uint32_t n_in = L.counters[WF_CNT_IN];
     const uint32_t lane = threadIdx.x & 63u;
 #ifdef RT_DIAG
@@ -359,7 +363,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
     T.o = T.d = T.r = mk(0.f, 0.f, 0.f);
     T.cur = T_DONE;
     T.sp = 0;
-    T.t_loc = RT_NAN;
+    T.t_loc = GB ? RT_INF : RT_NAN;
     T.best = Hit{RT_NONE, 0.f, 0.f, 0.f};
     T.fast = false;
     T.top_ref = 0u;
@@ -380,11 +384,11 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
                 const uint32_t j = L.order ? L.order[jq] : jq;
                 const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
                 const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
-                trav_init_stored(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r2.x, r2.y, r2.z), __float_as_uint(r2.w) != 0u);
+                trav_init_stored<GB>(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r2.x, r2.y, r2.z), __float_as_uint(r2.w) != 0u);
                 stk.reset();
             }
             for (;;) {
-                trav_pop_wave(T, stk); // every lane that has to unwind does, until none is left in T_POP
+                trav_pop_wave<GB>(T, stk); // every lane that has to unwind does, until none is left in T_POP
                 const uint32_t target = wave_min_u32(T.cur); // T_DONE is the largest value a lane can hold here
                 if (target == T_DONE)
                     break;
@@ -405,7 +409,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_EXT_WAVES_PER_SIMD) v
                     ConstF4 p = as_const_f4(S.scene.nodes + node_index);
                     const F4v r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
                     if (mine)
-                        trav_inner_apply<STATS>(T, stk, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), mk(r2.y, r2.z, r2.w), __float_as_uint(r3.x),
+                        trav_inner_apply<STATS, GB>(T, stk, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), mk(r2.y, r2.z, r2.w), __float_as_uint(r3.x),
                                                 __float_as_uint(r3.y), EPS, st);
                 } else { // a leaf: its triangles in index order, strict-less replacement (bvh.h:200-204,132)
                     const uint32_t cnt = RT_LEAF_CNT(target);
@@ -705,6 +709,39 @@ __global__ __launch_bounds__(256) void wf_resolve(const WfLaunch L, int first_pa
     }
 }
 
+// ------------------------------------------------------------------------------------------------ probe: rays in, hits out
+// rt_cast_rays_ex: arbitrary rays go through the SAME closest-hit kernels the renderer launches. wf_from_rays writes them as
+// queue records (what wf_generate / wf_shade write for their rays), wf_hits_out turns the hit records into the probe's output.
+__global__ __launch_bounds__(256) void wf_from_rays(const WfLaunch L, const float *rays, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0)
+        L.counters[WF_CNT_IN] = n;
+    if (i >= n)
+        return;
+    const V3 o = ld3(rays + 6ull * i), d = ld3(rays + 6ull * i + 3);
+    float4 *rq = reinterpret_cast<float4 *>(L.paths_in + i);
+    rq[0] = make_float4(o.x, o.y, o.z, d.x);
+    rq[1] = make_float4(d.y, d.z, __uint_as_float(i), __uint_as_float(1u));
+    rq[2] = make_float4(1.0f / d.x, 1.0f / d.y, 1.0f / d.z, __uint_as_float(ray_fast_ok_ray(o, d) ? 1u : 0u));
+    *reinterpret_cast<uint4 *>(rq + 3) = make_uint4(0u, 0u, 0u, 0u);
+}
+__global__ __launch_bounds__(256) void wf_hits_out(const DevScene S, const WfLaunch L, uint32_t n, uint32_t *prim_out, float *bct_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float4 hq = *reinterpret_cast<const float4 *>(L.hits + i);
+    const uint32_t k = __float_as_uint(hq.x);
+    if (k == RT_NONE) {
+        prim_out[i] = RT_NONE;
+        bct_out[3ull * i] = bct_out[3ull * i + 1] = bct_out[3ull * i + 2] = 0.0f;
+    } else {
+        prim_out[i] = (k & RT_PRIM_FLAG) ? S.n_triangles + (k & ~RT_PRIM_FLAG) : S.scene.tris[k].prim;
+        bct_out[3ull * i] = hq.y;
+        bct_out[3ull * i + 1] = hq.z;
+        bct_out[3ull * i + 2] = hq.w;
+    }
+}
+
 } // namespace
 
 namespace rt {
@@ -717,6 +754,49 @@ namespace rt {
         if (hipError_t le_ = RT_LAUNCH_CHECKED(__VA_ARGS__); le_ != hipSuccess) \
             return le_;                                 \
     } while (0)
+
+// the closest-hit kernel of one bounce: packets for coherent primary rays or the per-lane persistent kernel, each in the
+// reference's traversal order (near-local pruning, the parity mode) or with global-best pruning (L.global_best, production)
+static hipError_t launch_extend(const DevScene &S, const WfLaunch &L, bool packet, bool stats, int ext_blocks, hipStream_t stream) {
+    const dim3 grid(ext_blocks), block(256);
+    const bool gb = L.global_best != 0u;
+#define EXT_CASE(P, ST, G)                                                                          \
+    if (packet == P && stats == ST && gb == G) {                                                    \
+        if (P)                                                                                      \
+            return RT_LAUNCH_CHECKED((wf_extend_packet<ST, G>), grid, block, 0, stream, S, L);      \
+        return RT_LAUNCH_CHECKED((wf_extend<ST, G>), grid, block, 0, stream, S, L);                 \
+    }
+    EXT_CASE(false, false, false)
+    EXT_CASE(false, false, true)
+    EXT_CASE(false, true, false)
+    EXT_CASE(false, true, true)
+    EXT_CASE(true, false, false)
+    EXT_CASE(true, false, true)
+    EXT_CASE(true, true, false)
+    EXT_CASE(true, true, true)
+#undef EXT_CASE
+    return hipErrorInvalidValue;
+}
+
+// ---- closest-hit probe through the production kernels (rt_cast_rays_ex): rays -> queue -> wf_extend / wf_extend_packet -> hits
+hipError_t launch_wavefront_cast(const DevScene &S, WfLaunch L, const float *rays, uint32_t n, bool packet, bool stats, uint32_t *prim, float *bct,
+                                 hipStream_t stream) {
+    const dim3 block(256);
+    hipError_t e = hipMemsetAsync(L.counters, 0, sizeof(uint32_t) * WF_CNT_WORDS, stream);
+    if (e != hipSuccess)
+        return e;
+    L.n_paths = n;
+    L.order = nullptr;
+    L.packet_census = nullptr;
+    const int blocks = (int)((n + 255u) / 256u);
+    WF_LAUNCH(wf_from_rays, dim3(blocks), block, 0, stream, L, rays, n);
+    if ((e = launch_extend(S, L, packet, stats, (int)(L.stack_stride / 256u), stream)) != hipSuccess)
+        return e;
+    if (S.n_prims)
+        WF_LAUNCH(wf_extend_prims, dim3(blocks), block, 0, stream, S, L);
+    WF_LAUNCH(wf_hits_out, dim3(blocks), block, 0, stream, S, L, n, prim, bct);
+    return hipSuccess;
+}
 
 hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int num_cus, bool first_pass, bool last_pass, hipStream_t stream,
                                  EventPool *extend_events, unsigned long long *packet_census_out) {
@@ -776,14 +856,8 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         hipEvent_t e1 = e0 ? extend_events->next() : nullptr;
         if (e0 && e1)
             (void)hipEventRecord(e0, stream);
-        if (b == 0 && packet && stats) // coherent primary rays
-            WF_LAUNCH((wf_extend_packet<true>), dim3(ext_blocks), block, 0, stream, S, L);
-        else if (b == 0 && packet)
-            WF_LAUNCH((wf_extend_packet<false>), dim3(ext_blocks), block, 0, stream, S, L);
-        else if (stats)
-            WF_LAUNCH((wf_extend<true>), dim3(ext_blocks), block, 0, stream, S, L);
-        else
-            WF_LAUNCH((wf_extend<false>), dim3(ext_blocks), block, 0, stream, S, L);
+        if (hipError_t xe = launch_extend(S, L, b == 0 && packet, stats, ext_blocks, stream); xe != hipSuccess)
+            return xe;
         if (e0 && e1)
             (void)hipEventRecord(e1, stream);
         if (S.n_prims)
