@@ -155,6 +155,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--bvh", default="reference", choices=["reference", "device"],
                     help="reference: host build in the reference's exact topology (parity mode, the headline); device: LBVH built on the GPU (production mode: same closest hits, other topology)")
+    ap.add_argument("--wide", action="store_true", help="production build: collapse the scene BVH into the 8-wide quantised tree (RT_BUILD_WIDE) and walk that")
     ap.add_argument("--traversal", default="reference", choices=["reference", "global"],
                     help="reference: the reference's traversal order and pruning (parity mode, the headline); global: prune against the global best hit (production: fewer node visits, same hits)")
     args = ap.parse_args()
@@ -190,7 +191,7 @@ def main() -> None:
     tex_size = args.tex_size or wl["tex_size"]
     n_pix = W * H
     full_size = (W, H, n_tri, tex_size) == (wl["width"], wl["height"], wl["triangles"], wl["tex_size"]) and spp == wl["spp_per_gpu"] * world
-    workload_id = (args.workload if full_size else f"{args.workload}-custom") + ("" if args.bvh == "reference" else "-lbvh") + ("-gbest" if gbest else "")
+    workload_id = (args.workload if full_size else f"{args.workload}-custom") + ("" if args.bvh == "reference" else "-lbvh") + ("-gbest" if gbest else "") + ("-wide" if args.wide else "")
 
     t0 = time.time()
     scene = rt.scenegen.room_scene(n_tri, seed=SEED, tex_size=tex_size, n_tex_sets=16, n_materials=64, n_lights=16,
@@ -198,7 +199,7 @@ def main() -> None:
                                    camera=rt.scenegen.look_camera((-15.0, 4.0, 0.0), yaw_deg=-90.0, yfov=0.9, aspect=W / H))
     t_gen = time.time() - t0
     t0 = time.time()
-    dev = rt.DeviceScene(scene, device=local_rank, device_bvh=args.bvh == "device")
+    dev = rt.DeviceScene(scene, device=local_rank, device_bvh=args.bvh == "device", wide=args.wide)
     t_create = time.time() - t0
     build_times = dev.build_times()
 
@@ -363,7 +364,7 @@ def main() -> None:
                 "triangles": int(scene.n_triangles),
                 "sharding": f"interleaved {SHARD_ROWS}-row tiles over {world} GPU(s), RCCL gather of the {'rgb8 image' if film else 'float3 framebuffer'}" if world > 1 else "single GPU",
                 "film": "device (rt_render_rgb8)" if film else "none (linear float3)",
-                "traversal": "global-best pruning (production)" if gbest else "reference order and pruning (parity mode)",
+                "traversal": "8-wide quantised BVH, global-best culling, octant order (production)" if args.wide else "global-best pruning (production)" if gbest else "reference order and pruning (parity mode)",
                 "bvh": "reference topology, host build (parity mode)" if args.bvh == "reference" else "LBVH built on the device (production mode: identical closest hits, different topology and counters)",
             },
             "roofline": roofline,

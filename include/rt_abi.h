@@ -134,8 +134,14 @@ typedef struct rt_scene_desc {
  *   RT_BUILD_DEVICE_LBVH: on the GPU (Morton sort + Karras radix tree + refit, csrc/rt_bvh_device.hip), tens of milliseconds
  *       for 10^7 triangles instead of seconds. Same closest hits (identical t), but a different topology: ties between
  *       equal-t triangles may resolve differently and the counters differ. Production mode for big scenes; also selected by
- *       the environment variable RT_BVH_DEVICE=1. The light BVH (emissive triangles only) is always built on the host. */
-enum { RT_BUILD_REFERENCE = 0, RT_BUILD_DEVICE_LBVH = 1 };
+ *       the environment variable RT_BVH_DEVICE=1. The light BVH (emissive triangles only) is always built on the host.
+ *   RT_BUILD_WIDE (may be combined with either binary builder): the binary tree is collapsed into an 8-wide tree whose nodes
+ *       hold eight child boxes quantised conservatively to 8 bits per plane (80 B per node), chosen by a surface-area
+ *       dynamic program; the wavefront pipeline then walks THAT tree with global-best culling and octant-ordered slots
+ *       (csrc/wide_build.cpp, csrc/rt_wide.hip). Production mode: the closest hit is the reference's (t bit for bit; another
+ *       index only on exact ties) with far fewer memory accesses per ray; event counters count wide nodes. The megakernel /
+ *       reference-RNG parity renders are refused on such a scene (RT_ERR_UNSUPPORTED). Environment: RT_BVH_WIDE=1. */
+enum { RT_BUILD_REFERENCE = 0, RT_BUILD_DEVICE_LBVH = 1, RT_BUILD_WIDE = 2 };
 #define RT_MAX_PRIMITIVES 4096u
 
 typedef struct rt_params {
@@ -259,6 +265,10 @@ int rt_bvh_info(rt_scene *scene, int which, uint32_t *n_nodes, uint32_t *n_objec
  * right, pad, pad}; a child ref is an inner index, or 0x80000000 | count << 27 | first triangle for a leaf. tris48: n_tris
  * records of 12 words {a.xyz, (b-a).xyz, (c-a).xyz, original triangle index, flags, pad}. Pass NULL buffers for the counts. */
 int rt_bvh_device_dump(rt_scene *scene, int which, uint32_t *n_inner, uint32_t *n_tris, uint32_t *root, uint32_t *nodes64, uint32_t *tris48);
+/* The 8-wide scene BVH of a scene built with RT_BUILD_WIDE, copied back from HBM: nodes80 = n_nodes records of 20 words
+ * (layout: WideNode, csrc/rt_device_types.h — origin xyz, exponents + inner mask, first inner child, first triangle, triangle
+ * mask, pad, then qlo[3][8] and qhi[3][8] bytes); tris48 as in rt_bvh_device_dump, in the wide tree's order. NULL buffers: counts. */
+int rt_bvh_wide_dump(rt_scene *scene, uint32_t *n_nodes, uint32_t *n_tris, uint32_t *depth, uint32_t *nodes80, uint32_t *tris48);
 /* Wall time of the last rt_create's scene-BVH build in ms: {host build + flatten, 0} or {device build, upload of the raw arrays}. */
 int rt_build_times(const rt_scene *scene, double *build_ms, double *upload_ms);
 

@@ -48,6 +48,12 @@ int rt_film_table(float thr[256], uint32_t special[3]);
 int rt_bvh_build_host(const float *positions, uint32_t n_triangles, const uint32_t *subset, uint32_t n_subset, uint32_t *n_nodes, uint32_t *root,
                       uint32_t *nodes_out, uint32_t *order_out);
 
+/* The production build (RT_BUILD_WIDE, include/rt_abi.h) on the host, no GPU: the reference-topology tree of all triangles collapsed
+ * into the 8-wide quantised tree. nodes80: 20 words per node (WideNode, csrc/rt_device_types.h), root = node 0; order_out: original
+ * triangle index of triangle record k. Pass nodes80 = NULL to query n_nodes. */
+int rt_bvh_wide_build_host(const float *positions, uint32_t n_triangles, float cost_node, float cost_tri, uint32_t *n_nodes, uint32_t *depth,
+                           double *sah_cost, uint32_t *nodes80, uint32_t nodes_capacity, uint32_t *order_out);
+
 /* Texture::load_img (geometry.h:584-598: stbi_load with 4 channels forced) for the formats this loader reads, told apart by
  * their signatures: PNG (every colour type / bit depth / Adam7 / tRNS) and JPEG (baseline, extended-sequential and progressive
  * Huffman, 8 bit, 1 or 3 components, any sampling factors that divide the maximum, restart intervals). Both return the bytes

@@ -24,6 +24,7 @@ from ._ctypes_abi import (
     RT_FLAG_COUNTERS,
     RT_FLAG_DEVICE_FB,
     RT_BUILD_DEVICE_LBVH,
+    RT_BUILD_WIDE,
     RT_FLAG_MEGAKERNEL,
     RT_FLAG_GLOBAL_BEST,
     RT_CAST_PROBE,
@@ -139,17 +140,18 @@ def _as_desc(scene) -> Tuple[RtSceneDesc, object]:
 class DeviceScene:
     """Device-resident scene + both BVHs: the RaytracerStaticContext of raytracer.h:434-455, in HBM."""
 
-    def __init__(self, scene, device=0, device_bvh: bool = False):
+    def __init__(self, scene, device=0, device_bvh: bool = False, wide: bool = False):
         """`device_bvh`: build the scene BVH on the GPU (RT_BUILD_DEVICE_LBVH: production mode, different topology) instead
-        of the reference-topology host build. `device`: a HIP ordinal; RT_ALL_DEVICES (-1) for one replica per visible GPU + an RCCL communicator; or a list
+        of the reference-topology host build. `wide`: collapse that binary tree into the 8-wide quantised tree (RT_BUILD_WIDE:
+        production traversal). `device`: a HIP ordinal; RT_ALL_DEVICES (-1) for one replica per visible GPU + an RCCL communicator; or a list
         of ordinals (rt_create_on). Multi-GPU scenes shard every render over their GPUs and gather on the first one."""
         desc, keep = _as_desc(scene)
         self._keep = keep
         self._h = C.c_void_p()
-        if device_bvh:  # a private copy of the descriptor with the build flag set
+        if device_bvh or wide:  # a private copy of the descriptor with the build flags set
             d2 = RtSceneDesc()
             C.memmove(C.byref(d2), C.byref(desc), C.sizeof(RtSceneDesc))
-            d2.build_flags = RT_BUILD_DEVICE_LBVH
+            d2.build_flags = (RT_BUILD_DEVICE_LBVH if device_bvh else 0) | (RT_BUILD_WIDE if wide else 0)
             desc = d2
         if isinstance(device, (list, tuple)):
             devs = (C.c_int * len(device))(*[int(d) for d in device])
@@ -272,6 +274,15 @@ class DeviceScene:
         _check(lib().rt_bvh_device_dump(self._h, which, C.byref(ni), C.byref(nt), C.byref(root), u32ptr(nodes), u32ptr(tris)))
         return {"root": root.value, "nodes": nodes, "tris": tris}
 
+    def bvh_wide_dump(self):
+        """The 8-wide scene BVH read back from HBM: {depth, nodes (n,20) u32 (WideNode records), tris (n_tris,12) u32}."""
+        nn, nt, dp = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib().rt_bvh_wide_dump(self._h, C.byref(nn), C.byref(nt), C.byref(dp), None, None))
+        nodes = np.zeros((nn.value, 20), dtype=np.uint32)
+        tris = np.zeros((nt.value, 12), dtype=np.uint32)
+        _check(lib().rt_bvh_wide_dump(self._h, C.byref(nn), C.byref(nt), C.byref(dp), u32ptr(nodes), u32ptr(tris)))
+        return {"depth": dp.value, "nodes": nodes, "tris": tris}
+
     def build_times(self):
         b, u = C.c_double(), C.c_double()
         _check(lib().rt_build_times(self._h, C.byref(b), C.byref(u)))
@@ -298,6 +309,22 @@ def bvh_build_host(positions: np.ndarray, subset: Optional[np.ndarray] = None) -
     if rc != RT_OK:
         raise RtError(rc, "rt_bvh_build_host")
     return {"root": root.value, "nodes": nodes[: nn.value].copy(), "order": order}
+
+
+def bvh_wide_build_host(positions: np.ndarray, cost_node: float = 1.0, cost_tri: float = 0.3) -> dict:
+    """The production build (RT_BUILD_WIDE) on the host, no GPU needed: {nodes (n,20) u32 WideNode records, order, depth, sah_cost}."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 9)
+    n = pos.shape[0]
+    nn, depth, cost = C.c_uint32(), C.c_uint32(), C.c_double()
+    rc = lib().rt_bvh_wide_build_host(fptr(pos), n, cost_node, cost_tri, C.byref(nn), C.byref(depth), C.byref(cost), None, 0, None)
+    if rc != RT_OK:
+        raise RtError(rc, "rt_bvh_wide_build_host")
+    nodes = np.zeros((nn.value, 20), dtype=np.uint32)
+    order = np.zeros(n, dtype=np.uint32)
+    rc = lib().rt_bvh_wide_build_host(fptr(pos), n, cost_node, cost_tri, C.byref(nn), C.byref(depth), C.byref(cost), u32ptr(nodes), nn.value, u32ptr(order))
+    if rc != RT_OK:
+        raise RtError(rc, "rt_bvh_wide_build_host")
+    return {"nodes": nodes, "order": order, "depth": depth.value, "sah_cost": cost.value}
 
 
 def tonemap(fb: np.ndarray) -> np.ndarray:

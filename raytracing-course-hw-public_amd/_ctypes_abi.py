@@ -14,6 +14,7 @@ RT_PRIM_ELLIPSOID = 1
 RT_PRIM_PLANE = 2
 RT_BUILD_REFERENCE = 0
 RT_BUILD_DEVICE_LBVH = 1
+RT_BUILD_WIDE = 2
 RT_TEX_NONE = -1
 RT_RNG_DEVICE = 0
 RT_RNG_REFERENCE = 1
@@ -148,6 +149,7 @@ ABI_PROTOTYPES = {
     "rt_cast_rays": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, c_u32_p, c_float_p]),
     "rt_cast_rays_ex": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, C.c_uint32, c_u32_p, c_float_p, C.POINTER(RtStats)]),
     "rt_light_pdf": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, c_float_p]),
+    "rt_bvh_wide_dump": (C.c_int, [C.c_void_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
     "rt_bvh_info": (C.c_int, [C.c_void_p, C.c_int, c_u32_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
     "rt_tonemap_rgb8": (None, [c_float_p, C.c_size_t, c_u8_p]),
     "rt_render_rgb8": (C.c_int, [C.c_void_p, C.POINTER(RtParams), C.c_void_p, C.POINTER(RtStats)]),
@@ -174,6 +176,7 @@ HOST_PROTOTYPES = {
     "rt_free": (None, [C.c_void_p]),
     "rt_film_table": (C.c_int, [c_float_p, c_u32_p]),
     "rt_bvh_build_host": (C.c_int, [c_float_p, C.c_uint32, c_u32_p, C.c_uint32, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
+    "rt_bvh_wide_build_host": (C.c_int, [c_float_p, C.c_uint32, C.c_float, C.c_float, c_u32_p, c_u32_p, C.POINTER(C.c_double), c_u32_p, C.c_uint32, c_u32_p]),
 }
 
 

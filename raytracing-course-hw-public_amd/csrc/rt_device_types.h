@@ -86,6 +86,31 @@ struct alignas(16) DevTexture {
 };
 static_assert(sizeof(DevTexture) == 32, "DevTexture must be 32 bytes");
 
+// ---- production traversal: the 8-wide BVH with quantised child boxes (RT_BUILD_WIDE; wide_build.cpp, rt_wide.hip)
+// One 80-byte record = five 16-byte pieces holds EIGHT child boxes, each quantised conservatively (floor / ceil) to 8 bits per
+// plane on a per-node grid: origin p, per-axis power-of-two cell size 2^(e - 127). A lane that tests eight boxes pays 5 vector-L1
+// accesses; the binary DevNode pays 4 for two boxes, and the L1 access rate is wf_extend's roof (profiles/r02_l1_roof.txt).
+// After Ylitie, Karras, Laine, "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs" (HPG 2017), re-cut:
+//   * child slot s sits towards the corner (s&1 ? +x : -x, s&2 ? +y : -y, s&4 ? +z : -z) of the node, so that a ray whose
+//     direction signs are `oct` visits the hit slots in the order of decreasing (s ^ oct ^ 7): front to back without sorting;
+//   * inner children (bit s of imask) are consecutive records from child_base, in slot order;
+//   * the triangles of the node's leaf slots are consecutive DevTri records from tri_base: bit 3s + j of tri_mask says that leaf
+//     slot s holds a j-th triangle (at most 3 per slot), and that triangle is record tri_base + popcount(tri_mask below the bit).
+// An empty slot has an inverted box (qlo 255, qhi 0) that no ray hits.
+struct alignas(16) WideNode {
+    float p[3];           // grid origin = the node box's lower corner
+    uint8_t e[3];         // biased exponents: cell size on axis a = 2^(e[a] - 127)
+    uint8_t imask;        // bit s: slot s is an inner node
+    uint32_t child_base;  // first inner child (index into WideNode[])
+    uint32_t tri_base;    // first triangle of this node's leaf slots (index into DevTri[] / DevAttr[])
+    uint32_t tri_mask;    // 24 bits, see above
+    uint32_t pad;
+    uint8_t qlo[3][8];    // [axis][slot]
+    uint8_t qhi[3][8];
+};
+static_assert(sizeof(WideNode) == 80, "WideNode must be 80 bytes");
+#define RT_WIDE_MAX_LEAF_TRIS 3u
+
 struct DevBvh {
     const DevNode *nodes;
     const DevTri *tris;
@@ -93,6 +118,10 @@ struct DevBvh {
     uint32_t n_tris; // BVH::objects.size()
     uint32_t fast_ok; // every node box coordinate is 0 or has magnitude in [2^-37, 2^40] (div_exact_fast precondition)
     uint32_t lds_inner; // light BVH only: 0, or 1 + number of inner nodes when nodes + triangles + aux fit RT_SHADE_LIGHTS_F4 (wf_shade stages them in LDS)
+    const WideNode *wide; // scene BVH only: non-null = the scene was built wide (RT_BUILD_WIDE); root is wide[0], `nodes` is null,
+                          // `tris` (and DevScene::attrs) are in the wide tree's triangle order
+    uint32_t n_wide;
+    uint32_t pad_;
 };
 #define RT_SHADE_LIGHTS_F4 384 /* 6 KB of LDS in wf_shade: 4 pieces per inner node + 4 per light triangle (e.g. 31 nodes + 64 lights) */
 

@@ -24,6 +24,7 @@
 #include "rt_film.h"
 #include "rt_group.h"
 #include "rt_kernels.h"
+#include "wide_build.h"
 
 namespace {
 
@@ -84,6 +85,10 @@ struct rt_scene {
     std::vector<void *> owned;
     rt::HostBvh host_bvh[2];
     bool device_built = false; // scene BVH built by rt_bvh_device.hip: host_bvh[0] is reconstructed from HBM on demand
+    bool wide_built = false;   // RT_BUILD_WIDE: the scene BVH in HBM is the 8-wide quantised tree (wide_build.cpp); host_bvh[0] is the
+                               // binary tree it was collapsed from when that one was built on the host
+    uint32_t wide_depth = 0;
+    double wide_ms = 0, wide_cost = 0;
     uint32_t dev_n_inner[2] = {0, 0};
     double build_ms = 0, build_upload_ms = 0;
     uint32_t *d_counter = nullptr;
@@ -297,11 +302,33 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
         if (!((e[0] == 0) & (e[1] == 0) & (e[2] == 0)))
             lights.push_back(i);
     }
-    const char *env_dev = std::getenv("RT_BVH_DEVICE");
+    const char *env_dev = std::getenv("RT_BVH_DEVICE"), *env_wide = std::getenv("RT_BVH_WIDE");
     const bool dev_build = n > 0 && ((d->build_flags & RT_BUILD_DEVICE_LBVH) || (env_dev && std::atoi(env_dev) != 0));
+    const bool wide_build = n > 0 && ((d->build_flags & RT_BUILD_WIDE) || (env_wide && std::atoi(env_wide) != 0));
     rt::FlatBvh flat[2];
     rt::DeviceBvh dbvh{};
+    rt::WideBvh wide;
+    std::vector<DevTri> wide_tris;
     std::vector<DevAttr> attrs;
+    // shading records in the order of the triangle records `tris` (to_intersection_info's inputs, bvh.h:80-121)
+    auto make_attrs = [&](const std::vector<DevTri> &tris) {
+        attrs.resize(tris.size());
+        for (size_t k = 0; k < attrs.size(); ++k) {
+            const uint32_t t = tris[k].prim;
+            DevAttr &a = attrs[k];
+            std::memset(&a, 0, sizeof(a));
+            std::memcpy(a.n, d->normals + 9 * (size_t)t, 36);
+            std::memcpy(a.tg, d->tangents + 9 * (size_t)t, 36);
+            std::memcpy(a.uv, d->texcoords + 6 * (size_t)t, 24);
+            const DevTri &tr = tris[k];
+            V3h c = cross_h({tr.v[0], tr.v[1], tr.v[2]}, {tr.u[0], tr.u[1], tr.u[2]}); // triangle::normal geometry.h:477-479
+            float l = len_h(c);
+            a.gn[0] = c.x / l;
+            a.gn[1] = c.y / l;
+            a.gn[2] = c.z / l;
+            a.material = d->material_ids[t];
+        }
+    };
     // The geometry half of rt_create — both BVH builds, flattening, shading records — runs on a thread of its own while
     // this thread lays out the texture pool below (SURVEY 8f-2 "overlap"): on S-sponza the two halves take about as long
     // as each other (BVH 0.10 s, 268 MB of tiled / interleaved texels 0.2 s).
@@ -315,33 +342,69 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
             hipError_t be = rt::build_bvh_device(d, s->stream, &dbvh, &what);
             if (be != hipSuccess)
                 return std::make_pair(be == hipErrorOutOfMemory ? (int)RT_ERR_OOM : (int)RT_ERR_HIP, std::string("device BVH build: ") + what + ": " + hipGetErrorString(be));
-            s->owned.push_back(dbvh.nodes);
-            s->owned.push_back(dbvh.tris);
-            s->owned.push_back(dbvh.attrs);
             s->device_built = true;
             s->build_ms = dbvh.build_ms;
             s->build_upload_ms = dbvh.upload_ms;
+            if (!wide_build) {
+                s->owned.push_back(dbvh.nodes);
+                s->owned.push_back(dbvh.tris);
+                s->owned.push_back(dbvh.attrs);
+            }
         } else {
             s->host_bvh[0] = rt::build_bvh(d->positions, n, all);
-            flat[0] = rt::flatten_bvh(s->host_bvh[0], d->positions);
-            s->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
-            // ---- shading records in scene-BVH order
-            attrs.resize(flat[0].tris.size());
-            for (size_t k = 0; k < attrs.size(); ++k) {
-                const uint32_t t = flat[0].tris[k].prim;
-                DevAttr &a = attrs[k];
-                std::memset(&a, 0, sizeof(a));
-                std::memcpy(a.n, d->normals + 9 * (size_t)t, 36);
-                std::memcpy(a.tg, d->tangents + 9 * (size_t)t, 36);
-                std::memcpy(a.uv, d->texcoords + 6 * (size_t)t, 24);
-                const DevTri &tr = flat[0].tris[k];
-                V3h c = cross_h({tr.v[0], tr.v[1], tr.v[2]}, {tr.u[0], tr.u[1], tr.u[2]}); // triangle::normal geometry.h:477-479
-                float l = len_h(c);
-                a.gn[0] = c.x / l;
-                a.gn[1] = c.y / l;
-                a.gn[2] = c.z / l;
-                a.material = d->material_ids[t];
+            if (!wide_build) {
+                flat[0] = rt::flatten_bvh(s->host_bvh[0], d->positions);
+                make_attrs(flat[0].tris);
             }
+            s->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
+        }
+        if (wide_build) {
+            // ---- production build: collapse the binary tree (reference topology, or the LBVH read back from HBM) into the
+            // 8-wide quantised tree; triangle and shading records follow the wide tree's own order
+            const auto tw0 = std::chrono::steady_clock::now();
+            rt::BinBvh bin;
+            if (dev_build) {
+                std::vector<DevNode> hn(dbvh.n_inner);
+                std::vector<DevTri> ht(dbvh.n_tris);
+                hipError_t ce = hipSuccess;
+                if (dbvh.n_inner)
+                    ce = hipMemcpy(hn.data(), dbvh.nodes, sizeof(DevNode) * hn.size(), hipMemcpyDeviceToHost);
+                if (ce == hipSuccess && dbvh.n_tris)
+                    ce = hipMemcpy(ht.data(), dbvh.tris, sizeof(DevTri) * ht.size(), hipMemcpyDeviceToHost);
+                (void)hipFree(dbvh.nodes);
+                (void)hipFree(dbvh.tris);
+                (void)hipFree(dbvh.attrs);
+                if (ce != hipSuccess)
+                    return std::make_pair((int)RT_ERR_HIP, std::string("wide build: reading the device BVH back: ") + hipGetErrorString(ce));
+                bin = rt::bin_from_device(hn, ht, dbvh.root);
+                dbvh.nodes = nullptr, dbvh.tris = nullptr, dbvh.attrs = nullptr;
+            } else {
+                bin = rt::bin_from_host(s->host_bvh[0]);
+            }
+            float cn = 1.0f, ct = 0.3f;
+            if (const char *e = std::getenv("RT_WIDE_COST_NODE"))
+                cn = (float)std::atof(e);
+            if (const char *e = std::getenv("RT_WIDE_COST_TRI"))
+                ct = (float)std::atof(e);
+            wide = rt::build_wide(bin, d->positions, cn, ct);
+            wide_tris.resize(wide.order.size());
+            for (size_t k = 0; k < wide_tris.size(); ++k) {
+                const float *p = d->positions + 9 * (size_t)wide.order[k];
+                DevTri &t = wide_tris[k];
+                for (int c = 0; c < 3; ++c) {
+                    t.a[c] = p[c];
+                    t.v[c] = p[3 + c] - p[c]; // triangle::v geometry.h:473
+                    t.u[c] = p[6 + c] - p[c]; // triangle::u geometry.h:475
+                }
+                t.prim = wide.order[k];
+                t.flags = 0;
+                t.pad = 0;
+            }
+            make_attrs(wide_tris);
+            s->wide_built = true;
+            s->wide_depth = wide.depth;
+            s->wide_cost = wide.sah_cost;
+            s->wide_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
         }
         s->host_bvh[1] = rt::build_bvh(d->positions, n, lights);
         flat[1] = rt::flatten_bvh(s->host_bvh[1], d->positions);
@@ -497,6 +560,19 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
     int rc;
     for (int w = 0; w < 2; ++w) {
         DevBvh &b = w == 0 ? D.scene : D.lights;
+        if (w == 0 && wide_build) {
+            if ((rc = upload(wide.nodes, &b.wide, s->owned)) != RT_OK)
+                return rc;
+            if ((rc = upload(wide_tris, &b.tris, s->owned)) != RT_OK)
+                return rc;
+            b.nodes = nullptr;
+            b.root = wide.nodes.empty() ? RT_NONE : 0u;
+            b.n_tris = (uint32_t)wide_tris.size();
+            b.n_wide = (uint32_t)wide.nodes.size();
+            b.fast_ok = 0u;
+            s->dev_n_inner[0] = 0;
+            continue;
+        }
         if (w == 0 && dev_build) {
             b.nodes = dbvh.nodes;
             b.tris = dbvh.tris;
@@ -516,7 +592,7 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
         b.lds_inner = w == 1 ? light_lds_inner(flat[w]) : 0u;
         s->dev_n_inner[w] = (uint32_t)flat[w].nodes.size();
     }
-    if (dev_build)
+    if (dev_build && !wide_build)
         D.attrs = dbvh.attrs;
     else if ((rc = upload(attrs, &D.attrs, s->owned)) != RT_OK)
         return rc;
@@ -704,6 +780,9 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
     if (blocks < 1)
         blocks = 1;
     const bool wavefront = p->rng_mode == RT_RNG_DEVICE && !(p->flags & RT_FLAG_MEGAKERNEL);
+    if (s->wide_built && !wavefront)
+        return rt::fail(RT_ERR_UNSUPPORTED, "rt_render: a scene built with RT_BUILD_WIDE renders through the wavefront pipeline only (the megakernel and "
+                                            "the reference-RNG parity mode walk the reference's binary tree: create the scene without RT_BUILD_WIDE)");
     s->ext_events.reset();
     // everything from here to the final synchronisation is queued on the scene's stream; a failure in between must not
     // return while kernels are still in flight (a later ensure_wavefront / rt_destroy would free memory under them)
@@ -878,6 +957,8 @@ extern "C" int rt_cast_rays(rt_scene *s, const float *rays, uint32_t n, uint32_t
         return rt::fail(RT_ERR_INVALID_ARG, "rt_cast_rays: null argument");
     if (n == 0)
         return RT_OK;
+    if (s->wide_built) // no binary tree in HBM: the probe goes through the renderer's own wide kernel
+        return rt_cast_rays_ex(s, rays, n, RT_CAST_EXTEND, prim_out, bct_out, nullptr);
     HIP_TRY(hipSetDevice(s->device));
     DevBuf b_rays, b_bct, b_prim;
     HIP_TRY(b_rays.alloc((size_t)n * 24));
@@ -904,7 +985,7 @@ extern "C" int rt_cast_rays(rt_scene *s, const float *rays, uint32_t n, uint32_t
 extern "C" int rt_cast_rays_ex(rt_scene *s, const float *rays, uint32_t n, uint32_t mode, uint32_t *prim_out, float *bct_out, rt_stats *stats) {
     if (s && s->group)
         return rt_cast_rays_ex(rt::group_primary(s->group), rays, n, mode, prim_out, bct_out, stats);
-    if (mode == RT_CAST_PROBE) {
+    if (mode == RT_CAST_PROBE && !(s && s->wide_built)) {
         if (stats)
             std::memset(stats, 0, sizeof(*stats));
         return rt_cast_rays(s, rays, n, prim_out, bct_out);
@@ -991,6 +1072,8 @@ extern "C" int rt_bvh_device_dump(rt_scene *s, int which, uint32_t *n_inner, uin
         return rt::fail(RT_ERR_INVALID_ARG, "rt_bvh_device_dump: bad argument");
     if (s->group)
         return rt_bvh_device_dump(rt::group_primary(s->group), which, n_inner, n_tris, root, nodes64, tris48);
+    if (which == 0 && s->wide_built)
+        return rt::fail(RT_ERR_UNSUPPORTED, "rt_bvh_device_dump: the scene BVH is the 8-wide tree (RT_BUILD_WIDE): use rt_bvh_wide_dump");
     const DevBvh &b = which == 0 ? s->dev.scene : s->dev.lights;
     if (n_inner)
         *n_inner = s->dev_n_inner[which];
@@ -1001,6 +1084,28 @@ extern "C" int rt_bvh_device_dump(rt_scene *s, int which, uint32_t *n_inner, uin
     HIP_TRY(hipSetDevice(s->device));
     if (nodes64 && s->dev_n_inner[which])
         HIP_TRY(hipMemcpy(nodes64, b.nodes, sizeof(DevNode) * (size_t)s->dev_n_inner[which], hipMemcpyDeviceToHost));
+    if (tris48 && b.n_tris)
+        HIP_TRY(hipMemcpy(tris48, b.tris, sizeof(DevTri) * (size_t)b.n_tris, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_bvh_wide_dump(rt_scene *s, uint32_t *n_nodes, uint32_t *n_tris, uint32_t *depth, uint32_t *nodes80, uint32_t *tris48) {
+    if (!s)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_bvh_wide_dump: null argument");
+    if (s->group)
+        return rt_bvh_wide_dump(rt::group_primary(s->group), n_nodes, n_tris, depth, nodes80, tris48);
+    if (!s->wide_built)
+        return rt::fail(RT_ERR_UNSUPPORTED, "rt_bvh_wide_dump: the scene was not built with RT_BUILD_WIDE");
+    const DevBvh &b = s->dev.scene;
+    if (n_nodes)
+        *n_nodes = b.n_wide;
+    if (n_tris)
+        *n_tris = b.n_tris;
+    if (depth)
+        *depth = s->wide_depth;
+    HIP_TRY(hipSetDevice(s->device));
+    if (nodes80 && b.n_wide)
+        HIP_TRY(hipMemcpy(nodes80, b.wide, sizeof(WideNode) * (size_t)b.n_wide, hipMemcpyDeviceToHost));
     if (tris48 && b.n_tris)
         HIP_TRY(hipMemcpy(tris48, b.tris, sizeof(DevTri) * (size_t)b.n_tris, hipMemcpyDeviceToHost));
     return RT_OK;
@@ -1114,6 +1219,8 @@ extern "C" int rt_bvh_info(rt_scene *s, int which, uint32_t *n_nodes, uint32_t *
         return rt::fail(RT_ERR_INVALID_ARG, "rt_bvh_info: bad argument");
     if (s->group)
         return rt_bvh_info(rt::group_primary(s->group), which, n_nodes, n_objects, root, nodes_out, order_out);
+    if (which == 0 && s->device_built && s->wide_built)
+        return rt::fail(RT_ERR_UNSUPPORTED, "rt_bvh_info: the binary tree of a device-built wide scene is not kept");
     if (which == 0 && s->device_built && s->host_bvh[0].nodes.empty() && s->dev.scene.n_tris)
         if (int rc = reconstruct_host_bvh(s); rc != RT_OK)
             return rc;

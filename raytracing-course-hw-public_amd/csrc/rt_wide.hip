@@ -1,0 +1,316 @@
+// rt_wide.hip — closest hit through the 8-wide BVH with quantised child boxes (WideNode, rt_device_types.h): the production
+// traversal of the wavefront pipeline (scenes created with RT_BUILD_WIDE). Same queue protocol as wf_extend (rt_wavefront.hip):
+// persistent wavefronts, lanes refilled from the ray queue as their traversals end, hits stored at the ray's queue position.
+//
+// What replaces the reference's recursion (BVH::intersect_ray, src/bvh.h:195-235):
+//   * a node visit tests EIGHT child boxes from one 80-byte record (5 vector-L1 accesses per lane; the binary node costs 4 for
+//     two boxes and the L1 access rate is what bounds wf_extend, profiles/r02_l1_roof.txt);
+//   * every box is culled against the GLOBAL best hit so far (the reference prunes only between siblings, bvh.h:216-223);
+//   * no distance sort: a node's slots are laid out by octant (wide_build.cpp), so the hit slots are visited front to back by
+//     taking them in the order of decreasing (slot ^ oct ^ 7), oct = the ray's direction signs; the pending rest of a node is
+//     ONE 8-byte stack frame {first child index, pending slots | inner-slot mask}, whatever the number of hit children;
+//   * triangles are tested exactly as everywhere else (tri_hit, rt_device_lib.h: the reference's Cramer solve, bvh.h:36-65), in
+//     wave-wide batches like wf_extend's leaf batches, so a hit's (b, c, t) are bit-equal to the reference's for that triangle.
+// The boxes are NOT the reference's (8-bit conservative supersets, slab test by fused multiply-adds with an explicit error
+// margin instead of IEEE division): a ray can only see MORE boxes than exact arithmetic would allow, never fewer, so every
+// triangle the reference finds is found; on exact ties another triangle index may win. Checked against the CPU oracle in
+// tests/test_gpu_production.py (t bit-equal on every ray, index differences counted and confined to ties).
+#include "rt_device_lib.h"
+#include "rt_kernels.h"
+
+namespace {
+
+#ifndef RT_WIDE_WAVES_PER_SIMD
+#define RT_WIDE_WAVES_PER_SIMD 5
+#endif
+#ifndef RT_WIDE_LDS_DEPTH
+#define RT_WIDE_LDS_DEPTH 8 /* stacked node groups kept in LDS per lane (8 B each); deeper ones spill to the overflow workspace */
+#endif
+#ifndef RT_WIDE_CHUNK
+#define RT_WIDE_CHUNK 128u
+#endif
+#ifndef RT_WIDE_REFILL_MIN
+#define RT_WIDE_REFILL_MIN 16
+#endif
+#ifndef RT_WIDE_TRI_MIN
+#define RT_WIDE_TRI_MIN 20 /* run a triangle batch once this many lanes wait with pending triangles */
+#endif
+#define RT_WIDE_COOP_MAX 8u /* triangles one lane contributes to a batch; more stay pending for the next one */
+
+struct WTrav {
+    V3 o, d, idir;     // idir: 1/d with tiny components clamped (see wide_init)
+    uint32_t oct_inv;  // 7 ^ direction-sign octant
+    uint32_t gx, gy;   // current node group: first inner child of the node | pending slots by priority (bits 31..24), inner-slot mask (bits 7..0)
+    uint32_t top_x, top_y; // newest stacked group, cached in registers
+    int sp;
+    uint32_t tbase, tm, tall; // pending triangles of the node just tested: DevTri base, hit bits, all bits (for the compact index)
+    Hit best;          // best.t = +inf until the first hit
+    bool done;
+};
+
+DEV void wide_init(WTrav &T, const DevBvh &bvh, V3 o, V3 d, V3 r) {
+    T.o = o;
+    T.d = d;
+    // a direction component of (almost) zero would make 0 * inf = NaN in the slab terms: clamp |1/d| to 2^60. The slab then spans
+    // (-huge, +huge) for an origin inside it, is empty for one outside, and the boundary case counts as inside (conservative).
+    const float big = 1152921504606846976.0f; // 2^60
+    T.idir.x = __builtin_fabsf(d.x) < 8.673617379884035e-19f ? __builtin_copysignf(big, d.x) : r.x;
+    T.idir.y = __builtin_fabsf(d.y) < 8.673617379884035e-19f ? __builtin_copysignf(big, d.y) : r.y;
+    T.idir.z = __builtin_fabsf(d.z) < 8.673617379884035e-19f ? __builtin_copysignf(big, d.z) : r.z;
+    const uint32_t oct = (T.idir.x < 0.0f ? 1u : 0u) | (T.idir.y < 0.0f ? 2u : 0u) | (T.idir.z < 0.0f ? 4u : 0u);
+    T.oct_inv = 7u ^ oct;
+    T.gx = 0u;
+    T.gy = bvh.n_wide != 0u ? 0x80000000u : 0u; // "slot oct of a node whose children start at record 0": the root, whatever oct is (imask 0)
+    T.top_x = T.top_y = 0u;
+    T.sp = 0;
+    T.tbase = T.tm = T.tall = 0u;
+    T.best = Hit{RT_NONE, 0.f, 0.f, RT_INF};
+    T.done = false;
+}
+
+DEV float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u); } // v_cvt_f32_ubyteK
+
+// One node visit: take the next child of the current group (pushing the rest back if any), fetch its record and test its
+// eight boxes against [EPS, best.t]. Leaves the child's own group in (gx, gy) and its hit triangles in (tbase, tm, tall).
+template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const WideNode *nodes, STK &stk, LaneStats<STATS> &st) {
+    const uint32_t hits = T.gy;
+    const uint32_t bit = 31u - (uint32_t)__clz((int)hits);
+    const uint32_t rest = hits ^ (1u << bit);
+    const uint32_t slot = (bit - 24u) ^ T.oct_inv;
+    const uint32_t idx = T.gx + (uint32_t)__popc(hits & 0xFFu & ((1u << slot) - 1u));
+    const bool more = (rest >> 24) != 0u;
+    if (more & (T.sp > 0))
+        stk.push(T.sp - 1, T.top_x, __uint_as_float(T.top_y)); // spill the previous top
+    T.top_x = more ? T.gx : T.top_x;
+    T.top_y = more ? rest : T.top_y;
+    T.sp += more ? 1 : 0;
+
+    const uint4 *p = reinterpret_cast<const uint4 *>(nodes + idx);
+    const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
+    st.node();
+    st.box(8);
+    const uint32_t ew = n0.w, imask = ew >> 24;
+    const float adx = __uint_as_float((ew & 255u) << 23) * T.idir.x, ady = __uint_as_float(((ew >> 8) & 255u) << 23) * T.idir.y,
+                adz = __uint_as_float(((ew >> 16) & 255u) << 23) * T.idir.z;
+    const float bx = (__uint_as_float(n0.x) - T.o.x) * T.idir.x, by = (__uint_as_float(n0.y) - T.o.y) * T.idir.y, bz = (__uint_as_float(n0.z) - T.o.z) * T.idir.z;
+    // t = q * ad + b stands for ((p + q * cell) - o) / d. Error margin: the two products and the sum are each rounded once
+    // (<= 3 half-ulps of the larger magnitude), 1/d itself is off by half an ulp: 2^-21 of (|b| + 255 |ad|) covers it 4x over.
+    const float ex = __builtin_fmaf(255.0f, __builtin_fabsf(adx), __builtin_fabsf(bx)) * 4.76837158203125e-07f,
+                ey = __builtin_fmaf(255.0f, __builtin_fabsf(ady), __builtin_fabsf(by)) * 4.76837158203125e-07f,
+                ez = __builtin_fmaf(255.0f, __builtin_fabsf(adz), __builtin_fabsf(bz)) * 4.76837158203125e-07f;
+    const float bx0 = bx - ex, bx1 = bx + ex, by0 = by - ey, by1 = by + ey, bz0 = bz - ez, bz1 = bz + ez;
+    // near / far planes per axis by the direction sign: words {slots 0..3, slots 4..7}
+    const bool nx = T.idir.x < 0.0f, ny = T.idir.y < 0.0f, nz = T.idir.z < 0.0f;
+    const uint32_t xn0 = nx ? n3.z : n2.x, xn1 = nx ? n3.w : n2.y, xf0 = nx ? n2.x : n3.z, xf1 = nx ? n2.y : n3.w;
+    const uint32_t yn0 = ny ? n4.x : n2.z, yn1 = ny ? n4.y : n2.w, yf0 = ny ? n2.z : n4.x, yf1 = ny ? n2.w : n4.y;
+    const uint32_t zn0 = nz ? n4.z : n3.x, zn1 = nz ? n4.w : n3.y, zf0 = nz ? n3.x : n4.z, zf1 = nz ? n3.y : n4.w;
+    const float tlim = T.best.t;
+    uint32_t h = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = i & 3;
+        const uint32_t wxn = i < 4 ? xn0 : xn1, wxf = i < 4 ? xf0 : xf1, wyn = i < 4 ? yn0 : yn1, wyf = i < 4 ? yf0 : yf1, wzn = i < 4 ? zn0 : zn1, wzf = i < 4 ? zf0 : zf1;
+        const float tx0 = __builtin_fmaf(ub(wxn, k), adx, bx0), ty0 = __builtin_fmaf(ub(wyn, k), ady, by0), tz0 = __builtin_fmaf(ub(wzn, k), adz, bz0);
+        const float tx1 = __builtin_fmaf(ub(wxf, k), adx, bx1), ty1 = __builtin_fmaf(ub(wyf, k), ady, by1), tz1 = __builtin_fmaf(ub(wzf, k), adz, bz1);
+        const float tmin = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, EPS));
+        const float tmax = fminf(fminf(tx1, ty1), fminf(tz1, tlim));
+        h |= tmin <= tmax ? (1u << i) : 0u;
+    }
+    // inner slots -> priority bits (slot ^ oct_inv): an xor of the bit INDEX = three conditional block swaps of the byte
+    uint32_t r = h & imask;
+    {
+        const uint32_t s1 = ((r & 0x55u) << 1) | ((r >> 1) & 0x55u);
+        r = (T.oct_inv & 1u) ? s1 : r;
+        const uint32_t s2 = ((r & 0x33u) << 2) | ((r >> 2) & 0x33u);
+        r = (T.oct_inv & 2u) ? s2 : r;
+        const uint32_t s4 = ((r & 0x0Fu) << 4) | (r >> 4);
+        r = (T.oct_inv & 4u) ? s4 : r;
+    }
+    T.gx = n1.x;
+    T.gy = (r << 24) | imask;
+    // leaf slots -> their triangles: every bit of the slot mask tripled, then only the triangles that exist
+    uint32_t l = h & ~imask & 255u;
+    l = (l | (l << 8)) & 0x0000F00Fu;
+    l = (l | (l << 4)) & 0x000C30C3u;
+    l = (l | (l << 2)) & 0x00249249u;
+    T.tbase = n1.y;
+    T.tall = n1.z;
+    T.tm = (l * 7u) & n1.z;
+}
+
+// Triangle batch, as wf_extend's leaf batch: the pending (ray, triangle) pairs of all waiting lanes are laid out densely over
+// the wave; a lane's result is the minimum of (t bits, triangle record) over its pairs: smallest t, lowest record on equal t.
+template <bool STATS>
+DEV void wide_tri_batch(WTrav &T, const DevBvh &bvh, bool waiting, uint16_t *s_owner, unsigned long long *s_min, float2 *s_bc, LaneStats<STATS> &st) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t have = waiting ? (uint32_t)__popc(T.tm) : 0u;
+    const uint32_t n = have < RT_WIDE_COOP_MAX ? have : RT_WIDE_COOP_MAX;
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { // exclusive prefix sum of n (0..8) over the wave, one ballot per bit plane
+        const unsigned long long m = __ballot((n >> b) & 1u);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        off += below << b;
+        total += (uint32_t)__popcll(m) << b;
+    }
+    // Owner table: position off + t belongs to (lane, compact record offset of the lane's t-th pending triangle). Every
+    // waiting lane writes all RT_WIDE_COOP_MAX entries, highest t first, without a per-entry predicate: an entry with t >= n
+    // lands on a position of a later lane, whose own store of that position is issued later and wins (see leaf_batch).
+    if (waiting) {
+        uint32_t m = T.tm;
+        uint16_t ent[RT_WIDE_COOP_MAX];
+#pragma unroll
+        for (int t = 0; t < (int)RT_WIDE_COOP_MAX; ++t) {
+            const uint32_t b = (uint32_t)(__ffs((int)m) - 1) & 31u;
+            const uint32_t rec = (uint32_t)__popc(T.tall & ((1u << b) - 1u)); // compact index of bit b
+            ent[t] = (uint16_t)(lane | (rec << 8));
+            m &= m - 1u;
+        }
+#pragma unroll
+        for (int t = (int)RT_WIDE_COOP_MAX - 1; t >= 0; --t) {
+            s_owner[off + t] = ent[t];
+            asm volatile("" ::: "memory"); // keep the stores in this order
+        }
+        s_min[lane] = ~0ull;
+        T.tm = m; // what did not fit this batch stays pending
+    }
+    __threadfence_block();
+    for (uint32_t q0 = 0; q0 < total; q0 += 64u) { // wave-uniform trip count
+        const uint32_t q = q0 + lane;
+        const bool valid = q < total;
+        const uint32_t ow = valid ? (uint32_t)s_owner[q] : 0u;
+        const int src = (int)(ow & 63u);
+        const uint32_t kk = (uint32_t)__shfl((int)T.tbase, src) + (ow >> 8);
+        const V3 o = mk(__shfl(T.o.x, src), __shfl(T.o.y, src), __shfl(T.o.z, src));
+        const V3 d = mk(__shfl(T.d.x, src), __shfl(T.d.y, src), __shfl(T.d.z, src));
+        if (valid) {
+            const float4 *p = reinterpret_cast<const float4 *>(bvh.tris + kk);
+            const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+            st.tri();
+            V3 xs;
+            if (tri_hit(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), o, d, EPS, xs)) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(xs.z) << 32) | (unsigned long long)kk;
+                atomicMin(&s_min[src], key);
+                __threadfence_block();
+                if (s_min[src] == key) // this pair leads its ray so far: publish its barycentrics
+                    s_bc[src] = make_float2(xs.x, xs.y);
+            }
+        }
+    }
+    __threadfence_block();
+    if (waiting) {
+        const unsigned long long key = s_min[lane];
+        if (key != ~0ull) {
+            const float t = __uint_as_float((uint32_t)(key >> 32));
+            const float2 bc = s_bc[lane];
+            if (T.best.t > t) { // strict: the first-found triangle keeps an exact tie (update_intersection, bvh.h:132)
+                T.best.k = (uint32_t)key;
+                T.best.b = bc.x;
+                T.best.c = bc.y;
+                T.best.t = t;
+            }
+        }
+    }
+}
+
+template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) void wf_extend_wide(const DevScene S, const WfLaunch L) {
+    __shared__ uint32_t s_stack[STACK_LDS_DWORDS_W(RT_WIDE_LDS_DEPTH, 2)];
+    __shared__ uint16_t s_owner_all[4][64 * RT_WIDE_COOP_MAX + RT_WIDE_COOP_MAX]; // + overshoot of the unpredicated owner stores
+    __shared__ unsigned long long s_min_all[4][64];
+    __shared__ float2 s_bc_all[4][64];
+    const uint32_t wave = threadIdx.x >> 6;
+    uint16_t *s_owner = s_owner_all[wave];
+    unsigned long long *s_min = s_min_all[wave];
+    float2 *s_bc = s_bc_all[wave];
+    LaneStats<STATS> st;
+    RT_DECLARE_RING_STACK_W(stk, RT_WIDE_LDS_DEPTH, 2, s_stack, L.stack_overflow, L.stack_stride);
+    const uint32_t n_in = L.counters[WF_CNT_IN];
+    const WideNode *nodes = S.scene.wide;
+    WTrav T;
+    T.o = T.d = T.idir = mk(0.f, 0.f, 0.f);
+    T.oct_inv = 0u;
+    T.gx = T.gy = T.top_x = T.top_y = 0u;
+    T.sp = 0;
+    T.tbase = T.tm = T.tall = 0u;
+    T.best = Hit{RT_NONE, 0.f, 0.f, RT_INF};
+    T.done = true;
+    uint32_t slot = RT_NONE;
+    bool exhausted = n_in == 0; // wave-uniform
+    uint32_t q_lo = 0, q_hi = 0;
+    for (;;) {
+        const bool idle = T.done;
+        const unsigned long long im = __ballot(idle);
+        const int n_idle = __popcll(im);
+        if (!exhausted && (n_idle >= RT_WIDE_REFILL_MIN || n_idle == (int)__popcll(__ballot(1)))) {
+            if (q_lo == q_hi) { // a new range of queue positions, one ticket atomic per chunk
+                uint32_t base = 0;
+                if ((threadIdx.x & 63u) == 0u)
+                    base = atomicAdd(L.counters + WF_CNT_TICKET, (uint32_t)RT_WIDE_CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base);
+                q_lo = base < n_in ? base : n_in;
+                q_hi = base + RT_WIDE_CHUNK < n_in ? base + RT_WIDE_CHUNK : n_in;
+                exhausted = q_lo == q_hi;
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+            const uint32_t avail = q_hi - q_lo;
+            if (idle && rank < avail) {
+                const uint32_t jq = q_lo + rank;
+                const uint32_t j = L.order ? L.order[jq] : jq;
+                const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
+                const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
+                slot = jq;
+                wide_init(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r2.x, r2.y, r2.z));
+                stk.reset();
+            }
+            q_lo += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
+        }
+        // unwind, once per trip, straight-line: a lane whose group has no pending slot and that has no pending triangle takes
+        // the newest stacked group, or has finished
+        {
+            const bool pop = !T.done & (T.tm == 0u) & ((T.gy >> 24) == 0u);
+            const bool go = pop & (T.sp != 0);
+            const bool fin = pop & (T.sp == 0);
+            const int nsp = T.sp - 1;
+            const bool refill = go & (nsp > 0);
+            uint32_t n_x;
+            float n_y, unused = 0.0f;
+            stk.pop_masked(nsp - 1, refill, n_x, n_y, unused);
+            T.gx = go ? T.top_x : T.gx;
+            T.gy = go ? T.top_y : T.gy;
+            T.sp = go ? nsp : T.sp;
+            T.top_x = refill ? n_x : T.top_x;
+            T.top_y = refill ? __float_as_uint(n_y) : T.top_y;
+            if (fin) {
+                *reinterpret_cast<float4 *>(L.hits + slot) = make_float4(__uint_as_float(T.best.k), T.best.b, T.best.c, T.best.k == RT_NONE ? 0.0f : T.best.t);
+                T.done = true;
+            }
+        }
+        const bool waiting = !T.done && T.tm != 0u;
+        const bool stepper = !T.done && T.tm == 0u && (T.gy >> 24) != 0u;
+        const unsigned long long wm = __ballot(waiting), sm = __ballot(stepper);
+        if ((wm | sm) == 0ull) {
+            if (__ballot(!T.done) != 0ull)
+                continue; // only lanes that just popped an exhausted group: unwind again
+            if (exhausted)
+                break;
+            continue;
+        }
+        if (sm == 0ull || __popcll(wm) >= RT_WIDE_TRI_MIN)
+            wide_tri_batch<STATS>(T, S.scene, waiting, s_owner, s_min, s_bc, st);
+        else if (stepper)
+            wide_node_step<STATS>(T, nodes, stk, st);
+    }
+    st.flush(L.stats);
+}
+
+} // namespace
+
+namespace rt {
+
+hipError_t launch_extend_wide(const DevScene &S, const WfLaunch &L, bool stats, int blocks, hipStream_t stream) {
+    if (stats)
+        return RT_LAUNCH_CHECKED((wf_extend_wide<true>), dim3(blocks), dim3(256), 0, stream, S, L);
+    return RT_LAUNCH_CHECKED((wf_extend_wide<false>), dim3(blocks), dim3(256), 0, stream, S, L);
+}
+
+} // namespace rt
