@@ -1035,6 +1035,7 @@ extern "C" int rt_cast_rays_ex(rt_scene *s, const float *rays, uint32_t n, uint3
         stats->nodes_visited = h.nodes;
         stats->box_tests = h.box_tests;
         stats->tri_tests = h.tri_tests;
+        stats->light_queries = h.lq, stats->light_nodes = h.lnodes, stats->light_box_tests = h.lbox, stats->light_tri_tests = h.ltri, stats->light_hits = h.lhits; // 0 unless a census build
         float ms = 0;
         if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess)
             stats->kernel_ms = ms;

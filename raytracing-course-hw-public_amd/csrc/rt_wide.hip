@@ -106,6 +106,9 @@ template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const WideNod
     const uint32_t zn0 = nz ? n4.z : n3.x, zn1 = nz ? n4.w : n3.y, zf0 = nz ? n3.x : n4.z, zf1 = nz ? n3.y : n4.w;
     const float tlim = T.best.t;
     uint32_t h = 0u;
+#ifdef RT_WIDE_DIAG
+    bool diag_any_geo = false;
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int k = i & 3;
@@ -115,6 +118,10 @@ template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const WideNod
         const float tmin = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, EPS));
         const float tmax = fminf(fminf(tx1, ty1), fminf(tz1, tlim));
         h |= tmin <= tmax ? (1u << i) : 0u;
+#ifdef RT_WIDE_DIAG
+        if (tmin <= fminf(fminf(tx1, ty1), tz1))
+            diag_any_geo = true; // the ray meets this box somewhere, whatever the best hit says
+#endif
     }
     // inner slots -> priority bits (slot ^ oct_inv): an xor of the bit INDEX = three conditional block swaps of the byte
     uint32_t r = h & imask;
@@ -136,6 +143,16 @@ template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const WideNod
     T.tbase = n1.y;
     T.tall = n1.z;
     T.tm = (l * 7u) & n1.z;
+#ifdef RT_WIDE_DIAG // development census through the (otherwise idle) light counters of the instrumented variant
+    if (h == 0u)
+        st.lhit(); // a visit that hit none of the eight boxes
+    if (h == 0u && diag_any_geo)
+        st.lq(); // ... of which: only because the best hit is already closer (a distance-aware stack would have skipped the visit)
+    st.lbox((uint32_t)__popc(h & imask)); // inner children hit
+    st.ltri();                            // (visits, again: denominator)
+    if ((h & ~imask & 255u) != 0u)
+        st.lnode(); // visits with at least one leaf slot hit
+#endif
 }
 
 // Triangle batch, as wf_extend's leaf batch: the pending (ray, triangle) pairs of all waiting lanes are laid out densely over
