@@ -221,7 +221,6 @@ struct WfLaunch {
     uint32_t *sort_keys[2];  // sort workspace: keys / slot indices, double buffered
     uint32_t *sort_vals[2];
     void *sort_temp;
-    uint32_t *host_count;    // pinned host word for the queue-size read-back between bounces (null: no sorting)
     uint32_t use_packet;     // this pass's primary rays go through wf_extend_packet (rt_scene.cpp decides: RT_WF_PACKET, samples per
                              // pixel, and what the kernel's own census said on an earlier pass)
     unsigned long long *packet_census; // [2] device: trips, lanes served (summed over the launch's waves)

@@ -45,8 +45,16 @@ hipError_t launch_light_pdf(const DevScene &S, const float *rays, uint32_t n, fl
 // rt_wavefront.hip: one pass (pixel tile x sample range) of the wavefront pipeline, stream-ordered
 // `extend_events` (optional): one (start, stop) event pair per wf_extend launch is taken from the pool and recorded on `stream`
 // `packet_census_out` (optional, host, 2 words): trips and lanes served of this pass's wf_extend_packet launch (0, 0 if it did not run)
+// `host_sync` (optional): pinned words + events for the one-bounce-late read-back of the queue sizes (coherence sort and the
+// early stop need an upper bound of the queue on the host); without it bounces >= 1 run unsorted over the full pass
+struct WfHostSync {
+    uint32_t *counts;    // pinned host memory: word b = size of the queue entering bounce b; words WF_HOST_CENSUS_WORD.. = packet census
+    hipEvent_t *events;  // events[b] is recorded once counts[b] has been written
+    int n_events;
+};
+#define WF_HOST_CENSUS_WORD 40 /* 8-byte aligned, behind RT_MAX_RAY_DEPTH + 1 size words */
 hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int num_cus, bool first_pass, bool last_pass, hipStream_t stream,
-                                 EventPool *extend_events, unsigned long long *packet_census_out);
+                                 EventPool *extend_events, unsigned long long *packet_census_out, const WfHostSync *host_sync);
 // closest-hit probe through the renderer's own kernels: `rays` (6 floats each, device) -> queue -> wf_extend (or wf_extend_packet)
 // -> prim / bct (device). `L` carries the workspace (paths_in, hits, counters, stack_overflow, stats) and the traversal mode.
 hipError_t launch_wavefront_cast(const DevScene &S, WfLaunch L, const float *rays, uint32_t n, bool packet, bool stats, uint32_t *prim, float *bct,

@@ -153,7 +153,8 @@ struct rt_scene {
     uint32_t *wf_sort_keys[2] = {nullptr, nullptr}, *wf_sort_vals[2] = {nullptr, nullptr};
     void *wf_sort_temp = nullptr;
     size_t wf_sort_temp_bytes = 0;
-    uint32_t *wf_host_count = nullptr; // pinned, 8 words: [0] queue size, [2..5] wf_extend_packet's census
+    uint32_t *wf_host_count = nullptr; // pinned, 48 words: queue size per bounce, then wf_extend_packet's census (rt_kernels.h WfHostSync)
+    std::vector<hipEvent_t> wf_count_events; // one per bounce: "the size of the queue entering this bounce has reached wf_host_count"
     // wf_extend_packet (primary rays as coherent packets) pays off only while a wave's 64 rays stay together; its own census
     // (lanes served per trip) decides per configuration whether later passes and renders keep using it
     uint64_t pkt_key = 0; // width, height, samples per pass, shard count of the configuration pkt_off was measured on
@@ -230,6 +231,8 @@ struct rt_scene {
         (void)hipSetDevice(device);
         if (wf_host_count)
             (void)hipHostFree(wf_host_count);
+        for (hipEvent_t ev : wf_count_events)
+            (void)hipEventDestroy(ev);
         for (void *p : wf_owned)
             (void)hipFree(p);
         for (void *p : owned)
@@ -824,9 +827,15 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
         s->wf_bind(W);
         W.fb = d_fb;
         const char *sort_env = std::getenv("RT_WF_SORT");
-        if (!s->wf_host_count && hipHostMalloc((void **)&s->wf_host_count, 8 * sizeof(uint32_t)) != hipSuccess)
+        if (!s->wf_host_count && hipHostMalloc((void **)&s->wf_host_count, 48 * sizeof(uint32_t)) != hipSuccess)
             s->wf_host_count = nullptr;
-        W.host_count = s->wf_host_count;
+        while (s->wf_count_events.size() < RT_MAX_RAY_DEPTH + 1) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+                break;
+            s->wf_count_events.push_back(ev);
+        }
+        rt::WfHostSync hsync{s->wf_host_count, s->wf_count_events.data(), (int)s->wf_count_events.size()};
         W.sort_mode = sort_env ? (uint32_t)std::atoi(sort_env) : 4u; // 24-bit key: cell, octant, direction sub-cone (measured best)
         // production traversal: global-best pruning (rt_abi.h RT_FLAG_GLOBAL_BEST; RT_TRAVERSAL=global for callers without flags)
         const char *trav_env = std::getenv("RT_TRAVERSAL");
@@ -852,7 +861,7 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
                 W.use_packet = pkt_mode == 0 ? 0u : pkt_mode > 0 ? 1u : (W.pass_samples >= 16u && !s->pkt_off) ? 1u : 0u;
                 unsigned long long census[2] = {0ull, 0ull};
                 HIP_TRY(rt::launch_wavefront_pass(s->dev, W, counters, s->num_cus, s0 == 0, s0 + W.pass_samples >= p->samples, s->stream,
-                                                  stats ? &s->ext_events : nullptr, census));
+                                                  stats ? &s->ext_events : nullptr, census, s->wf_host_count ? &hsync : nullptr));
                 if (census[0] != 0ull && (double)census[1] < 33.0 * (double)census[0])
                     s->pkt_off = true;
             }

@@ -615,12 +615,20 @@ DEV uint32_t spread3(uint32_t v) { // 6 bits -> every third bit
 }
 // `direct`: no sort follows (sorting off or a tiny queue): the identity order over the dense index goes straight to sort_vals[1].
 // Either way this pass turns the dense ray index j < n into the physical slot of paths_in (sub-queue regions, WF_STRIPES).
-__global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLaunch L, int direct) {
+// `bound` >= n is what the HOST knows about the queue size when it launches this bounce (the size of the previous bounce's
+// queue, read back without stalling the device): the sort that follows runs over `bound` pairs, so positions [n, bound) get
+// the largest key and end up behind every real ray (nobody reads their order entries: consumers stop at n).
+__global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLaunch L, int direct, uint32_t bound) {
     __shared__ uint32_t s_run[WF_STRIPES + 1u];
     const uint32_t n = L.counters[WF_CNT_IN], n_slots = L.counters[WF_CNT_SLOTS];
     if (threadIdx.x <= WF_STRIPES)
         s_run[threadIdx.x] = L.stripes[WF_STRIPES * WF_STRIPE_WORDS + threadIdx.x];
     __syncthreads();
+    if (!direct)
+        for (uint32_t j = n + blockIdx.x * blockDim.x + threadIdx.x; j < bound; j += gridDim.x * blockDim.x) {
+            L.sort_keys[0][j] = 0xFFFFFFFFu;
+            L.sort_vals[0][j] = 0u;
+        }
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
         uint32_t pos = j;
         if (n_slots != 0u) { // run k holds dense indices [s_run[k], s_run[k+1])
@@ -801,7 +809,7 @@ hipError_t launch_wavefront_cast(const DevScene &S, WfLaunch L, const float *ray
 }
 
 hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int num_cus, bool first_pass, bool last_pass, hipStream_t stream,
-                                 EventPool *extend_events, unsigned long long *packet_census_out) {
+                                 EventPool *extend_events, unsigned long long *packet_census_out, const WfHostSync *host_sync) {
     const int gen_blocks = (int)((L.n_paths + 255u) / 256u < (uint32_t)num_cus * 16u ? (L.n_paths + 255u) / 256u : (uint32_t)num_cus * 16u);
     const dim3 block(256);
     hipError_t e = hipMemsetAsync(L.counters, 0, sizeof(uint32_t) * WF_CNT_WORDS, stream);
@@ -820,33 +828,34 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         WF_LAUNCH((wf_generate<false>), dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, S, L);
     const int ext_blocks = (int)(L.stack_stride / 256u); // rt_scene.cpp sizes the overflow workspace for exactly this grid
     const int shade_blocks = num_cus * RT_SHADE_BLOCKS_PER_CU;
-    uint32_t *h_count = L.host_count; // pinned word owned by the scene: per-bounce queue size read-back
-    uint32_t n_active = L.n_paths;
+    // Queue sizes reach the host one bounce LATE and without ever idling the device: after bounce b's wf_advance the size of
+    // queue b + 1 is copied to pinned word b + 1 and an event is recorded; bounce b + 2 waits for THAT event — by then bounce
+    // b + 1's kernels are queued behind it, so the device has a whole bounce of work while the host looks. The host needs the
+    // size only as an upper bound (grid of the ray-order pass, length of the sort, "nothing left": stop): the kernels read the
+    // exact size from device memory. (Round 2 synchronised the stream once per bounce: eight idle gaps per pass.)
+    const WfHostSync *hs = L.sort_mode != 0u || (packet && packet_census_out) ? host_sync : nullptr;
+    if (hs && (!hs->counts || !hs->events || hs->n_events < (int)L.ray_depth + 1))
+        hs = nullptr;
+    uint32_t bound = L.n_paths; // upper bound of the queue entering the bounce about to be launched
     for (uint32_t b = 0; b < L.ray_depth; ++b) {
         L.order = nullptr; // primary rays: dense and coherent as generated
         if (b > 0) {
-            bool sort = false;
-            if (h_count) {
-                if ((e = hipMemcpyAsync(h_count, L.counters + WF_CNT_IN, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+            if (hs && b >= 2) { // size of queue b - 1, an upper bound of queue b
+                if ((e = hipEventSynchronize(hs->events[b - 1])) != hipSuccess)
                     return e;
-                const bool read_census = b == 1 && packet && packet_census_out; // rides on the queue-size read-back: no extra sync
-                if (read_census && (e = hipMemcpyAsync(h_count + 2, L.packet_census, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream)) != hipSuccess)
-                    return e;
-                if ((e = hipStreamSynchronize(stream)) != hipSuccess)
-                    return e;
-                if (read_census)
-                    std::memcpy(packet_census_out, h_count + 2, 2 * sizeof(unsigned long long));
-                n_active = *h_count;
-                if (n_active == 0)
+                bound = hs->counts[b - 1];
+                if (b == 2 && packet && packet_census_out)
+                    std::memcpy(packet_census_out, hs->counts + WF_HOST_CENSUS_WORD, 2 * sizeof(unsigned long long));
+                if (bound == 0)
                     break;
-                sort = L.sort_mode != 0u && n_active >= 4096u;
             }
+            const bool sort = hs && L.sort_mode != 0u && bound >= 4096u;
             // dense ray index -> slot of paths_in (wf_shade's sub-queue regions), with the coherence keys when a sort follows
-            const uint32_t kb = (n_active + 255u) / 256u < (uint32_t)num_cus * 16u ? (n_active + 255u) / 256u : (uint32_t)num_cus * 16u;
-            WF_LAUNCH(wf_sort_keys, dim3(kb > 0 ? kb : 1), block, 0, stream, S, L, sort ? 0 : 1);
+            const uint32_t kb = (bound + 255u) / 256u < (uint32_t)num_cus * 16u ? (bound + 255u) / 256u : (uint32_t)num_cus * 16u;
+            WF_LAUNCH(wf_sort_keys, dim3(kb > 0 ? kb : 1), block, 0, stream, S, L, sort ? 0 : 1, bound);
             if (sort) {
                 size_t tmp = L.sort_temp_bytes;
-                hipError_t se = rocprim::radix_sort_pairs(L.sort_temp, tmp, L.sort_keys[0], L.sort_keys[1], L.sort_vals[0], L.sort_vals[1], (size_t)n_active, 0u, L.sort_mode == 4 ? 24u : 21u, stream);
+                hipError_t se = rocprim::radix_sort_pairs(L.sort_temp, tmp, L.sort_keys[0], L.sort_keys[1], L.sort_vals[0], L.sort_vals[1], (size_t)bound, 0u, L.sort_mode == 4 ? 24u : 21u, stream);
                 if (se != hipSuccess)
                     return se;
             }
@@ -874,6 +883,15 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         else
             WF_LAUNCH((wf_shade<false, false>), dim3(shade_blocks), block, 0, stream, S, L);
         WF_LAUNCH(wf_advance, dim3(1), dim3(64), 0, stream, L.counters, L.stripes);
+        if (hs && b + 1 < L.ray_depth) { // size of queue b + 1 -> pinned word b + 1 (read by bounce b + 2)
+            if ((e = hipMemcpyAsync(hs->counts + b + 1, L.counters + WF_CNT_IN, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+                return e;
+            if (b == 0 && packet && packet_census_out &&
+                (e = hipMemcpyAsync(hs->counts + WF_HOST_CENSUS_WORD, L.packet_census, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+                return e;
+            if ((e = hipEventRecord(hs->events[b + 1], stream)) != hipSuccess)
+                return e;
+        }
         WfPath *t = L.paths_in;
         L.paths_in = L.paths_out;
         L.paths_out = t;
