@@ -1,48 +1,57 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the render-loop hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload sponza|s10m]
+    python bench.py --gpus N --steps K --warmup W [--workload sponza|s10m] [--scaling auto|weak|strong] [--mode parity|global|wide]
 
 Metric (BASELINE.json): Msamples/s, whole job.
 
 Workloads (the reference ships no Sponza asset, so both are the deterministic synthetic sets it names):
   sponza (default, BASELINE config 3/4): "S-sponza" = 262 144 random triangles in a closed 40x16x20 room + 12 wall
          triangles + 16 emissive ceiling triangles, 16 procedural 1024^2 RGBA8 texture sets, 66 materials, white
-         environment, ray_depth 8; 1000x1000, 64 SPP per GPU.
+         environment, ray_depth 8; 1000x1000, 64 SPP per GPU (config 3), or 1000 SPP in all (config 4, --scaling strong).
   s10m   (BASELINE config 5): "S-10M" = the same recipe with 10^7 triangles (vertex offsets +-0.03), 2048x2048,
          32 SPP per GPU (256 SPP on 8 GPUs). Working set (nodes 0.64 GB + triangles 0.48 GB + attributes 1.28 GB) is far
          beyond the 256 MiB Infinity Cache: the configuration where HBM traffic / time / 8 TB/s is a real fraction.
+With no --workload the line describes S-sponza (config 3) and, on one GPU, carries config 5 as well: `extra_workloads.s10m`
+is the same measurement on S-10M taken in the same invocation (its CPU leg is skipped: the oracle's 10^7-triangle BVH build
+alone takes longer than the whole bench should).
 
 One step = one pass of the hot path over one batch = one full render of the image: rt_render_rgb8() through the C-ABI
 (render + the film on the device, i.e. what run_raytracer leaves in the reference's Image) with the image resident in
-HBM (RT_FLAG_DEVICE_FB) + for N > 1 the RCCL gather of the rgb8 image to rank 0 (--film none: rt_render() and the
-float3 framebuffer instead). Scene upload and BVH build happen once before the timed region, like the reference's
-RaytracerStaticContext (raytracer.h:633) precedes its pixel loop.
+HBM (RT_FLAG_DEVICE_FB) + for N > 1 the RCCL gather of the rgb8 image to rank 0. Scene upload and BVH build happen once
+before the timed region, like the reference's RaytracerStaticContext (raytracer.h:633) precedes its pixel loop.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the image is sharded in interleaved 8-row tiles
-(block b -> rank b % N), scene replicated per GPU; weak scaling: SPP = spp_per_gpu * N so per-GPU work is fixed.
+Traversal modes (--mode; the headline is ALWAYS parity unless --mode says otherwise, the others are reported beside it under
+"production" on one GPU):
+  parity  the reference's tree and traversal order (bvh.h:195-235, near-local pruning): hits, event counters and image are the
+          oracle's bit for bit. The headline.
+  global  same tree, every box culled against the global best hit (RT_FLAG_GLOBAL_BEST).
+  wide    the 8-wide BVH with quantised child boxes (RT_BUILD_WIDE): the production build.
 
-The "roofline" object (dominant kernel wf_extend):
-  achieved / frac      SURVEY 8d's ALGORITHMIC bytes (reference-layout record sizes x event counts from the instrumented
-                       kernel variant; cache hits are NOT subtracted) / the live HIP-event launch duration, against the
-                       nominal 8 TB/s. This is the contract's figure; it can exceed 1 when the working set is cache
-                       resident (S-sponza), so it must not be read as HBM utilisation.
-  traffic / hbm_frac   HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE) kept
-                       under profiles/ (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and stamped with the
-                       hash of the device sources they were measured on: used only
-                       while that hash matches the sources of this run, else null. hbm_frac = traffic / live launch
-                       duration / 8 TB/s is the fraction of the memory roofline actually used. request_frac = L2 read
-                       requests per launch / live launch duration / the ~55 G requests/s this chip sustains for random
-                       gathers of <= 64-B records (tools/ubench/gather64.hip, profiles/r02_gather64_calibration.txt): the
-                       practical roof of this kernel's access pattern, which is request-rate bound, not byte bound.
-  l1_frac              vector-L1 (TCP) tag accesses per clock per CU of wf_extend (same committed PMC profile) / the 0.98 the
-                       chip retires at most (tools/l1_roof_probe.sh, profiles/r02_l1_roof.txt). A 64-byte node costs four
-                       16-byte loads = four L1 accesses per lane whatever its cache residency: this is the roof that binds
-                       the kernel on both workloads (S-sponza 0.8 of it at HBM 0.2; S-10M 0.7 with 42 % miss stalls).
-  limiter + pmc        what the SQ/TCP/TCC counters of the same committed profile say binds the kernel (L1 access rate,
-                       VALU issue share, active lanes per VALU instruction, wave-wait share, hit rates), with its source file.
+N > 1, two ways to launch, same sharding (interleaved 8-row tiles, block b -> GPU b % N, scene replicated per GPU):
+  * python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...   one rank per GPU, dist.gather over RCCL;
+  * python bench.py --gpus N                                                   (WORLD_SIZE unset) ONE process: the library's own
+    multi-GPU scene (rt_create_on: a replica per GPU + ncclCommInitAll, csrc/rt_group.cpp) renders and gathers.
+Either way the line says n_gpus = N only if N GPUs really took part; fewer visible devices or a rank-count mismatch exit non-zero.
+--scaling weak: SPP = 64 x N (per-GPU work fixed). --scaling strong: BASELINE config 4 exactly, 1000x1000 at 1000 SPP in all.
+auto (default): strong at N = 8 (that IS config 4), weak otherwise.
+
+The "roofline" object (dominant kernel: the closest-hit kernel, wf_extend / wf_extend_packet / wf_extend_wide):
+  achieved / frac / traffic   HBM-SIDE bytes per launch (rocprofv3 PMC passes kept under profiles/, FETCH_SIZE doubled + WRITE_SIZE
+                       as MI355X_MICROARCH.md prescribes for gfx950, stamped with the hash of the device sources they were measured
+                       on and used only while that hash matches this run's sources) / the live HIP-event launch duration,
+                       against the nominal 8 TB/s. frac is therefore a real fraction of the memory roofline (< 1); null with
+                       the reason in traffic_source when no matching profile exists. frac_fetch_x1 is the same with FETCH_SIZE
+                       counted once: tools/ubench/gather64.hip shows this kernel's <= 64-byte gathers cost ONE request each,
+                       so x1 is what the workload's own calibration supports and x2 is the guide's upper bound.
+  algorithmic_GBps / algorithmic_over_peak   SURVEY 8d's ALGORITHMIC bytes (reference-layout record sizes x event counts from the
+                       instrumented kernel variant; cache hits are NOT subtracted) / the same launch time. Exceeds 1 when the
+                       working set is cache resident: a statement about work, not about HBM.
+  binding_roof         the roof that actually binds the kernel in the committed counter profile (vector-L1 access rate, or the
+                       HBM request rate for random gathers), its fraction and source.
+  request_frac, l1_frac, limiter, pmc   as measured in the same committed profile.
 "cpu_baseline": the CPU oracle (port of the reference algorithm, byte-identical to the reference binary on the
-fixtures) timed on this box's host cores on a bounded sample of the same workload; rank 0, N = 1 only.
+fixtures; profiles/r03_cpu_baseline_crosscheck.json times both) on this box's host cores on a bounded sample; rank 0, N = 1 only.
 """
 import argparse
 import hashlib
@@ -59,7 +68,8 @@ sys.path.insert(0, ROOT)
 SHARD_ROWS = 8
 SEED = 0x5EED5EED
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
+CONFIG4_SPP = 1000
 
 WORKLOADS = {
     "sponza": dict(label="S-sponza", width=1000, height=1000, spp_per_gpu=64, triangles=262144, offset=0.15, tex_size=1024, cpu_share=16,
@@ -67,12 +77,20 @@ WORKLOADS = {
     "s10m": dict(label="S-10M", width=2048, height=2048, spp_per_gpu=32, triangles=10_000_000, offset=0.03, tex_size=1024, cpu_share=256,
                  metric="Msamples/sec (whole node) on synthetic 10M-triangle scene 2048x2048"),
 }
-DEVICE_SOURCES = ("raytracing-course-hw-public_amd/csrc/rt_wavefront.hip", "raytracing-course-hw-public_amd/csrc/rt_device_lib.h",
-                  "raytracing-course-hw-public_amd/csrc/rt_device_types.h", "include/rt_devspec.h")
+# everything that decides what the closest-hit kernels do and how they are launched: kernels, layouts, the tree builders, the
+# launch geometry and workspace policy in rt_scene.cpp, and the compiler flags
+DEVICE_SOURCES = tuple("raytracing-course-hw-public_amd/csrc/" + f for f in (
+    "rt_wavefront.hip", "rt_wide.hip", "rt_device_lib.h", "rt_device_types.h", "rt_kernels.h", "rt_scene.cpp", "bvh_build.cpp", "wide_build.cpp",
+    "rt_bvh_device.hip", "Makefile")) + ("include/rt_devspec.h",)
+MODES = {
+    "parity": dict(suffix="", wide=False, gbest=False, text="reference tree, reference order and pruning (parity mode)"),
+    "global": dict(suffix="-gbest", wide=False, gbest=True, text="reference tree, global-best pruning (production)"),
+    "wide": dict(suffix="-wide", wide=True, gbest=False, text="8-wide quantised BVH, global-best culling, octant order (production build RT_BUILD_WIDE)"),
+}
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the device sources of the wavefront kernels: stamps PMC profiles so that a stale one is never quoted."""
+    """sha256 over the device-side sources: stamps PMC profiles so that a stale one is never quoted."""
     h = hashlib.sha256()
     for rel in DEVICE_SOURCES:
         with open(os.path.join(ROOT, rel), "rb") as f:
@@ -127,7 +145,7 @@ def load_profile(name: str, workload_id: str, src_hash: str):
 
 def measured_stream_peak():
     """Best streaming-read rate of the box class from the committed microbenchmark record (nominal peak stays 8 TB/s)."""
-    for rnd in (PROFILE_ROUND, "r01"):
+    for rnd in (PROFILE_ROUND, "r02", "r01"):
         rel = os.path.join("profiles", f"{rnd}_hbm_stream.txt")
         try:
             vals = [float(v) for v in re.findall(r"read\s+([0-9.]+)\s*GB/s", open(os.path.join(ROOT, rel)).read())]
@@ -138,40 +156,261 @@ def measured_stream_peak():
     return None, None
 
 
+def resolve_launch(gpus: int, env=None, visible_devices=None):
+    """How `--gpus N` is carried out. Returns (launcher, rank, local_rank, world): launcher is "single", "torchrun" (one process
+    per GPU, started by torch.distributed.run) or "group" (ONE process, the library's own multi-GPU scene). Raises SystemExit
+    when N GPUs cannot take part: a line claiming n_gpus = N must never come from fewer devices."""
+    env = os.environ if env is None else env
+    world = int(env.get("WORLD_SIZE", "1"))
+    rank, local_rank = int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0"))
+    if gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if world > 1:
+        if world != gpus:
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {gpus}")
+        return "torchrun", rank, local_rank, world
+    if gpus == 1:
+        return "single", 0, local_rank, 1
+    if visible_devices is not None and visible_devices < gpus:
+        raise SystemExit(f"--gpus {gpus} but only {visible_devices} GPU(s) visible: refusing to report a {gpus}-GPU number from fewer devices")
+    return "group", 0, 0, 1
+
+
+def resolve_spp(scaling: str, gpus: int, wl: dict, explicit_spp: int):
+    """(samples per pixel of the whole job, "weak" | "strong")."""
+    if explicit_spp > 0:
+        return explicit_spp, ("strong" if scaling == "strong" else "weak")
+    if scaling == "auto":
+        scaling = "strong" if gpus == 8 else "weak"
+    if scaling == "strong":
+        return CONFIG4_SPP, "strong"  # BASELINE config 4: 1000 SPP in all, whatever N
+    return wl["spp_per_gpu"] * gpus, "weak"
+
+
+def make_scene(rt, wl, n_tri, tex_size, aspect):
+    return rt.scenegen.room_scene(n_tri, seed=SEED, tex_size=tex_size, n_tex_sets=16, n_materials=64, n_lights=16,
+                                  light_strength=20.0, alpha_fraction=0.02, offset=wl["offset"],
+                                  camera=rt.scenegen.look_camera((-15.0, 4.0, 0.0), yaw_deg=-90.0, yfov=0.9, aspect=aspect))
+
+
+class Runner:
+    """One device scene (one traversal mode) of one workload: timed steps + the roofline record of its closest-hit kernel."""
+
+    def __init__(self, rt, torch, dist, scene, wl_name, mode, W, H, spp, launcher, rank, world, n_gpus, local_rank, backend, film, full_size, device_bvh=False):
+        """`full_size`: True (the workload's own geometry at its per-GPU SPP: the configuration the committed profiles describe),
+        "config4" (same geometry, 1000 SPP in all) or False (custom sizes)."""
+        self.rt, self.torch, self.dist = rt, torch, dist
+        self.wl_name, self.mode, self.m = wl_name, mode, MODES[mode]
+        self.W, self.H, self.spp, self.n_pix = W, H, spp, W * H
+        self.launcher, self.rank, self.world, self.n_gpus, self.backend, self.film = launcher, rank, world, n_gpus, backend, film
+        self.workload_id = (wl_name if full_size is True else f"{wl_name}-{full_size}" if full_size else f"{wl_name}-custom") + ("-lbvh" if device_bvh else "") + self.m["suffix"]
+        self.device = torch.device("cuda", local_rank)
+        t0 = time.time()
+        dev_arg = list(range(n_gpus)) if launcher == "group" else local_rank
+        self.dev = rt.DeviceScene(scene, device=dev_arg, wide=self.m["wide"], device_bvh=device_bvh)
+        self.t_create = time.time() - t0
+        self.build_times = self.dev.build_times()
+        self.ranks_formed = self.dev.n_devices if launcher == "group" else world
+        self.block = SHARD_ROWS * W
+        sharding = importlib.import_module("raytracing-course-hw-public_amd.sharding")
+        self.fb = torch.zeros(self.n_pix * 3, dtype=torch.float32, device=self.device)
+        self.img = torch.zeros(self.n_pix * 3, dtype=torch.uint8, device=self.device) if film else self.fb
+        self.gather_device = self.device if backend == "nccl" else torch.device("cpu")
+        self.gather = sharding.FramebufferGather(self.n_pix, self.block, rank, world, self.gather_device, dtype=self.img.dtype)
+        self.my_pixels = sharding.shard_pixels(self.n_pix, self.block, rank, world)
+        torch.cuda.synchronize()  # RT_FLAG_DEVICE_FB precondition (rt_abi.h): the zero-fills above ran on torch's stream
+
+    def shard_kw(self):
+        # torchrun: this rank renders its blocks; group: the library shards over its own GPUs (shard_count must stay 1)
+        if self.world > 1:
+            return dict(shard_index=self.rank, shard_count=self.world, shard_block=self.block)
+        return dict(shard_block=self.block if self.launcher == "group" else 0)
+
+    def step(self):
+        if self.film:
+            _, st = self.dev.run_raytracer_rgb8(self.W, self.H, self.spp, seed=SEED, device_rgb8=self.img.data_ptr(), global_best=self.m["gbest"], **self.shard_kw())
+        else:
+            _, st = self.dev.run_raytracer(self.W, self.H, self.spp, seed=SEED, device_fb=self.fb.data_ptr(), global_best=self.m["gbest"], **self.shard_kw())
+        # torchrun, N > 1: RCCL gather of this rank's interleaved blocks to rank 0 over xGMI (no-op at N = 1; inside the library for "group")
+        self.gather.gather(self.img if self.backend == "nccl" else self.img.cpu())
+        return st
+
+    def sync(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        kernel_ms, dom_ms, dom_launches = [], 0.0, 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st = self.step()
+            kernel_ms.append(st["kernel_ms"])
+            dom_ms += st["dominant_ms"]
+            dom_launches += st["dominant_launches"]
+        self.sync()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.gather_device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        self.elapsed, self.steps = elapsed, steps
+        self.kernel_ms, self.dom_ms, self.dom_launches = kernel_ms, dom_ms, dom_launches
+        return float(self.n_pix) * self.spp * steps / elapsed / 1e6
+
+    def roofline(self):
+        """Roofline record of the closest-hit kernel for the steps just timed. Event counters come from the instrumented kernel
+        variant on a bounded budget (<= 64 M samples) and are scaled to the step's sample count."""
+        cnt_spp = max(1, min(self.spp, (64 << 20) // max(1, self.my_pixels)))
+        _, cst = self.dev.run_raytracer(self.W, self.H, cnt_spp, seed=SEED, device_fb=self.fb.data_ptr(), counters=True, global_best=self.m["gbest"], **self.shard_kw())
+        scale = self.spp / cnt_spp
+        pixels_counted = self.my_pixels if self.launcher != "group" else self.n_pix
+        all_bytes = algorithmic_bytes(cst, 0) * scale + 12.0 * pixels_counted
+        trav_bytes = float(cst["box_tests"] * 24 + cst["nodes_visited"] * 16 + cst["tri_tests"] * 36) * scale
+        if self.launcher == "group":  # counters are summed over the GPUs, launches run concurrently: per-GPU share
+            trav_bytes /= self.n_gpus
+        launches = self.dom_launches / self.steps
+        launch_s = self.dom_ms / max(1, self.dom_launches) / 1e3
+        algorithmic = trav_bytes / launches / launch_s / 1e9
+        kernel_s = (sum(self.kernel_ms) / len(self.kernel_ms)) / 1e3
+        src_hash = kernel_source_hash()
+        traffic = traffic_x1 = requests = request_roof = None
+        traffic_source = "not collected: PMC counters cannot run inside the timed bench"
+        pmc, limiter, binding = None, None, None
+        if self.n_gpus == 1:
+            tj, traffic_source = load_profile("hbm_traffic", self.workload_id, src_hash)
+            if tj is not None:
+                traffic, traffic_x1 = tj.get("hbm_bytes_per_launch"), tj.get("hbm_bytes_per_launch_fetch_x1")
+                requests, request_roof = tj.get("read_requests_per_launch"), tj.get("request_roof_Greq_s")
+                traffic_source = (f"{tj['_file']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command on the same device "
+                                  "sources (hash checked); FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md; not measured in this run")
+            pj, pmc_source = load_profile("pmc_wf_extend", self.workload_id, src_hash)
+            if pj is not None:
+                pmc = {k: pj.get(k) for k in ("valu_busy", "lanes_per_valu", "wait_any_frac", "l1_hit", "l2_hit", "salu_per_valu", "l1_accesses_per_clk_per_cu",
+                                              "l1_roof_accesses_per_clk_per_cu", "l1_frac", "l1_miss_rate_Greq_s", "l1_pending_stall_frac", "shader_clock_ghz", "workload", "spp")}
+                pmc["source"] = pj["_file"] + " (earlier rocprofv3 --pmc run, same device sources)"
+                limiter = pj.get("limiter")
+            else:
+                pmc = {"source": None, "note": pmc_source}
+        hbm_rate = traffic / launch_s / 1e9 if traffic else None
+        request_frac = requests / launch_s / 1e9 / request_roof if requests and request_roof else None
+        l1_frac = pmc.get("l1_frac") if pmc else None
+        cands = [c for c in (("vector-L1 tag access rate (profiles/r02_l1_roof.txt: 0.98 accesses per clock per CU)", l1_frac),
+                             ("HBM request rate for random <= 64-byte gathers (profiles/r02_gather64_calibration.txt: 55 G requests/s)", request_frac),
+                             ("HBM bandwidth (8 TB/s nominal)", hbm_rate / HBM_PEAK_GBS if hbm_rate else None)) if c[1]]
+        if cands:
+            name, frac = max(cands, key=lambda c: c[1])
+            binding = {"name": name, "frac": round(frac, 4), "source": (pmc or {}).get("source") or traffic_source}
+        stream_peak, stream_src = measured_stream_peak()
+        kernel = ("wf_extend_wide<false> (8-wide quantised BVH, every bounce)" if self.m["wide"] else
+                  f"wf_extend<false, {'true' if self.m['gbest'] else 'false'}> (closest hit; primary rays through wf_extend_packet while its packets stay coherent)")
+        return {
+            "bound": "hbm",  # the roof the contract prices this path against (no dense contraction -> no MFMA roof)
+            "achieved": round(hbm_rate, 2) if hbm_rate else None,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(hbm_rate / HBM_PEAK_GBS, 4) if hbm_rate else None,
+            "achieved_is": "HBM-side bytes per closest-hit launch (committed PMC profile of the same sources: 2 x FETCH_SIZE + WRITE_SIZE) / live launch time; null when no matching profile exists (see traffic_source)",
+            "traffic": traffic,
+            "traffic_source": traffic_source,
+            "frac_fetch_x1": round(traffic_x1 / launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic_x1 else None,
+            "fetch_size_multiplier": "x2 is MI355X_MICROARCH.md's prescription (a streaming request moves a 128-B line); this kernel's gathers are <= 64-B records, for which "
+                                     "tools/ubench/gather64.hip measures ONE request per record (profiles/r02_gather64_calibration.txt): x1 (frac_fetch_x1) is what the workload's own calibration supports, x2 an upper bound",
+            "algorithmic_GBps": round(algorithmic, 2),
+            "algorithmic_over_peak": round(algorithmic / HBM_PEAK_GBS, 4),
+            "algorithmic_is": "SURVEY 8d: reference-layout record sizes x event counts (cache hits included) / live launch time; a statement about work done, it exceeds 1 when the working set is cache resident",
+            "binding_roof": binding,
+            "hbm_rate": round(hbm_rate, 2) if hbm_rate else None,
+            "hbm_frac": round(hbm_rate / HBM_PEAK_GBS, 4) if hbm_rate else None,
+            "request_rate_Greq_s": round(requests / launch_s / 1e9, 2) if requests else None,
+            "request_roof_Greq_s": request_roof,
+            "request_frac": round(request_frac, 4) if request_frac else None,
+            "l1_frac": l1_frac,
+            "limiter": limiter,
+            "pmc": pmc,
+            "peak_measured_read": stream_peak,
+            "peak_measured_source": stream_src,
+            "kernel": kernel + ": every closest-hit launch is timed",
+            "kernel_src_sha16": src_hash,
+            "launches_per_step": launches,
+            "avg_launch_ms": round(launch_s * 1e3, 4),
+            "algorithmic_bytes_per_launch": round(trav_bytes / launches, 1),
+            "pipeline": {  # all kernels of one rt_render (generate, extend, shade, resolve) against all algorithmic bytes
+                "algorithmic_GBps": round(all_bytes / kernel_s / 1e9, 2),
+                "device_ms_per_step": round(kernel_s * 1e3, 3),
+                "algorithmic_bytes_per_sample": round(all_bytes / (pixels_counted * self.spp), 1),
+                "casts_per_sample": round(cst["casts"] / max(1, cst["samples"]), 3),
+                "nodes_per_cast": round(cst["nodes_visited"] / max(1, cst["casts"]), 1),
+                "tri_tests_per_cast": round(cst["tri_tests"] / max(1, cst["casts"]), 1),
+            },
+        }
+
+    def close(self):
+        self.dev.close()
+
+
+def cpu_baseline_leg(rt, scene, wl, W, H, cpu_seconds):
+    """The oracle in reference-RNG + libm mode (the reference CPU path, raytracer.h:636-662) on every `share`-th 256-pixel
+    span of the same image, all host threads the cgroup grants, SPP chosen from a short probe to land near --cpu-seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+
+    t0 = time.time()
+    orc = oracle.OracleScene(scene)
+    t_build = time.time() - t0
+    cores = effective_cores()
+    share = wl["cpu_share"] if W * H >= 256 * wl["cpu_share"] * 4 else 16
+    _, p = orc.run_raytracer(W, H, 1, rng_mode=rt.RT_RNG_REFERENCE, shard_index=0, shard_count=share, shard_block=256, threads=cores)
+    rate = p["samples"] / (p["total_ms"] / 1e3)
+    cpu_spp = int(max(1, min(64, round(cpu_seconds * rate / p["samples"]))))
+    _, c = orc.run_raytracer(W, H, cpu_spp, rng_mode=rt.RT_RNG_REFERENCE, shard_index=0, shard_count=share, shard_block=256, threads=cores)
+    orc.close()
+    return {
+        "value": round(c["samples"] / (c["total_ms"] / 1e3) / 1e6, 4),
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": (f"same scene, every {share}th 256-pixel span of the {W}x{H} image at {cpu_spp} SPP = {c['samples']} samples, {c['total_ms'] / 1e3:.1f} s, "
+                   f"reference RNG + libm (BVH build {t_build:.1f} s excluded, as the GPU's is); port vs reference binary: profiles/r03_cpu_baseline_crosscheck.json"),
+    }
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="sponza", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: sponza, with S-10M as extra_workloads.s10m on one GPU")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"], help="strong = BASELINE config 4 (1000 SPP in all); auto: strong at 8 GPUs, weak otherwise")
+    ap.add_argument("--mode", default="parity", choices=sorted(MODES), help="traversal mode of the HEADLINE value (default parity; the others are reported under 'production')")
+    ap.add_argument("--bvh", default="reference", choices=["reference", "device"],
+                    help="binary builder: reference = host build in the reference's exact topology (the parity tree); device = LBVH built on the GPU (rt_bvh_device.hip). "
+                         "--mode wide collapses whichever is chosen")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default: the workload's SPP per GPU x gpus)")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel of the whole job (default: by --scaling)")
     ap.add_argument("--triangles", type=int, default=0)
     ap.add_argument("--tex-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline: no production-mode records, no extra workload")
     ap.add_argument("--film", default="device", choices=["device", "none"], help="device: rt_render_rgb8 (film on the GPU, rgb8 gathered); none: rt_render (float3 gathered)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 flow on fewer GPUs (all ranks on GPU 0, gather staged through host)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the torchrun flow on fewer GPUs (all ranks on GPU 0, gather staged through host)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
-    ap.add_argument("--bvh", default="reference", choices=["reference", "device"],
-                    help="reference: host build in the reference's exact topology (parity mode, the headline); device: LBVH built on the GPU (production mode: same closest hits, other topology)")
-    ap.add_argument("--wide", action="store_true", help="production build: collapse the scene BVH into the 8-wide quantised tree (RT_BUILD_WIDE) and walk that")
-    ap.add_argument("--traversal", default="reference", choices=["reference", "global"],
-                    help="reference: the reference's traversal order and pruning (parity mode, the headline); global: prune against the global best hit (production: fewer node visits, same hits)")
     args = ap.parse_args()
-    wl = WORKLOADS[args.workload]
-    gbest = args.traversal == "global"
+    wl_name = args.workload or "sponza"
+    wl = WORKLOADS[wl_name]
 
     import numpy as np  # noqa: F401
     import torch  # imported BEFORE the HIP library so that one HIP runtime serves both (same soname)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rt = importlib.import_module("raytracing-course-hw-public_amd")
+    in_process = int(os.environ.get("WORLD_SIZE", "1")) <= 1 and args.gpus > 1
+    launcher, rank, local_rank, world = resolve_launch(args.gpus, visible_devices=torch.cuda.device_count() if in_process else None)
     dist = None
-    if world > 1:
+    if launcher == "torchrun":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -182,198 +421,122 @@ def main() -> None:
     if args.backend == "gloo":
         local_rank = 0  # rehearsal: every rank renders on GPU 0
     torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    film = args.film == "device"
 
-    rt = importlib.import_module("raytracing-course-hw-public_amd")
     W, H = args.width or wl["width"], args.height or wl["height"]
-    spp = args.spp if args.spp > 0 else wl["spp_per_gpu"] * world
+    spp, scaling = resolve_spp(args.scaling, args.gpus, wl, args.spp)
     n_tri = args.triangles or wl["triangles"]
     tex_size = args.tex_size or wl["tex_size"]
-    n_pix = W * H
-    full_size = (W, H, n_tri, tex_size) == (wl["width"], wl["height"], wl["triangles"], wl["tex_size"]) and spp == wl["spp_per_gpu"] * world
-    workload_id = (args.workload if full_size else f"{args.workload}-custom") + ("" if args.bvh == "reference" else "-lbvh") + ("-gbest" if gbest else "") + ("-wide" if args.wide else "")
+    full_geometry = (W, H, n_tri, tex_size) == (wl["width"], wl["height"], wl["triangles"], wl["tex_size"])
+    full_size = (True if spp == wl["spp_per_gpu"] * args.gpus else "config4" if (spp == CONFIG4_SPP and wl_name == "sponza") else False) if full_geometry else False
 
     t0 = time.time()
-    scene = rt.scenegen.room_scene(n_tri, seed=SEED, tex_size=tex_size, n_tex_sets=16, n_materials=64, n_lights=16,
-                                   light_strength=20.0, alpha_fraction=0.02, offset=wl["offset"],
-                                   camera=rt.scenegen.look_camera((-15.0, 4.0, 0.0), yaw_deg=-90.0, yfov=0.9, aspect=W / H))
+    scene = make_scene(rt, wl, n_tri, tex_size, W / H)
     t_gen = time.time() - t0
-    t0 = time.time()
-    dev = rt.DeviceScene(scene, device=local_rank, device_bvh=args.bvh == "device", wide=args.wide)
-    t_create = time.time() - t0
-    build_times = dev.build_times()
+    common = dict(launcher=launcher, rank=rank, world=world, n_gpus=args.gpus, local_rank=local_rank, backend=args.backend, film=film, device_bvh=args.bvh == "device")
+    run = Runner(rt, torch, dist, scene, wl_name, args.mode, W, H, spp, full_size=full_size, **common)
+    if launcher == "group" and run.ranks_formed != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the library formed {run.ranks_formed} rank(s)")
+    value = run.timed(args.steps, args.warmup)
+    roofline = run.roofline()
+    elapsed = run.elapsed
+    setup = {"scene_generation": round(t_gen, 2), "rt_create_bvh_upload": round(run.t_create, 2), "scene_bvh_build": round(run.build_times["build_ms"] / 1e3, 4)}
+    run.close()
 
-    block = SHARD_ROWS * W
-    sharding = importlib.import_module("raytracing-course-hw-public_amd.sharding")
-    fb = torch.zeros(n_pix * 3, dtype=torch.float32, device=device)
-    film = args.film == "device"
-    img = torch.zeros(n_pix * 3, dtype=torch.uint8, device=device) if film else fb
-    gather_device = device if args.backend == "nccl" else torch.device("cpu")
-    gather = sharding.FramebufferGather(n_pix, block, rank, world, gather_device, dtype=img.dtype)
-    my_pixels = sharding.shard_pixels(n_pix, block, rank, world)
+    single = args.gpus == 1 and rank == 0
+    extras = single and not args.no_extras
+    x_steps, x_warm = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
 
-    def step():
-        if film:
-            _, st = dev.run_raytracer_rgb8(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_rgb8=img.data_ptr(), global_best=gbest)
-        else:
-            _, st = dev.run_raytracer(W, H, spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr(), global_best=gbest)
-        # N > 1: RCCL gather of this rank's interleaved blocks to rank 0 over xGMI (no-op at N = 1)
-        gather.gather(img if args.backend == "nccl" else img.cpu())
-        return st
+    def production_records(scene_, wl_name_, W_, H_, spp_, full_, parity_value, skip, steps_, warm_):
+        out = {}
+        for mode in ("global", "wide"):
+            if mode == skip:
+                continue
+            r = Runner(rt, torch, dist, scene_, wl_name_, mode, W_, H_, spp_, full_size=full_, **common)
+            v = r.timed(steps_, warm_)
+            rf = r.roofline()
+            out[mode] = {"traversal": MODES[mode]["text"], "workload_id": r.workload_id, "value": round(v, 3), "unit": "Msamples/s", "steps": steps_, "warmup": warm_,
+                         "ms_per_step": round(r.elapsed / steps_ * 1e3, 3), "vs_parity": round(v / parity_value, 3) if parity_value else None,
+                         "rt_create_s": round(r.t_create, 2), "roofline": rf}
+            r.close()
+        out["parity_of_these_modes"] = ("tests/test_gpu_production.py, against the CPU oracle: closest-hit t bit-equal on every ray (5 fixtures, S-sponza 60 000 rays, S-10M 100 000 rays), "
+                                        "index differences only on exact ties, the S-sponza 1000x1000x1 SPP framebuffer bit-identical to the oracle's; the wide tree may find a hit "
+                                        "1 ulp CLOSER than the reference where the reference's own pruning skips it (coplanar overlapping triangles): counted there")
+        return out
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    torch.cuda.synchronize()  # RT_FLAG_DEVICE_FB precondition (rt_abi.h): the zero-fills above ran on torch's stream
-    for _ in range(args.warmup):
-        step()
-    sync()
-    kernel_ms, dom_ms, dom_launches = [], 0.0, 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = step()
-        kernel_ms.append(st["kernel_ms"])
-        dom_ms += st["dominant_ms"]
-        dom_launches += st["dominant_launches"]
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    total_samples = float(n_pix) * spp * args.steps
-    value = total_samples / elapsed / 1e6
-
-    # ---- roofline of the dominant kernel, wf_extend (closest-hit traversal): algorithmic bytes per launch / average
-    # launch duration. Its algorithmic bytes are the scene-BVH traversal terms of SURVEY 8d (box tests x 24 + nodes x 16 +
-    # triangle tests x 36); one render = `dominant_launches` launches (passes x bounces). Counters are per-sample event
-    # counts; they are collected on a bounded budget (<= 64 M samples) and scaled to the step's sample count.
-    cnt_spp = max(1, min(spp, (64 << 20) // max(1, my_pixels)))
-    _, cst = dev.run_raytracer(W, H, cnt_spp, seed=SEED, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr(), counters=True, global_best=gbest)
-    scale = spp / cnt_spp
-    all_bytes = algorithmic_bytes(cst, 0) * scale + 12.0 * my_pixels
-    trav_bytes = float(cst["box_tests"] * 24 + cst["nodes_visited"] * 16 + cst["tri_tests"] * 36) * scale
-    launches_per_render = dom_launches / args.steps
-    avg_launch_s = dom_ms / max(1, dom_launches) / 1e3
-    achieved = trav_bytes / launches_per_render / avg_launch_s / 1e9
-    avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
-
-    src_hash = kernel_source_hash()
-    traffic, traffic_source = None, "not collected: PMC counters cannot run inside the timed bench"
-    pmc, limiter, requests, request_roof = None, None, None, None
-    if world == 1:
-        tj, traffic_source = load_profile("hbm_traffic", workload_id, src_hash)
-        if tj is not None:
-            traffic = tj.get("hbm_bytes_per_launch")
-            requests, request_roof = tj.get("read_requests_per_launch"), tj.get("request_roof_Greq_s")
-            traffic_source = (f"{tj['_file']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command on the same device "
-                              "sources (hash checked); FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md; not measured in this run")
-        pj, pmc_source = load_profile("pmc_wf_extend", workload_id, src_hash)
-        if pj is not None:
-            pmc = {k: pj.get(k) for k in ("valu_busy", "lanes_per_valu", "wait_any_frac", "l1_hit", "l2_hit", "salu_per_valu", "l1_accesses_per_clk_per_cu",
-                                          "l1_roof_accesses_per_clk_per_cu", "l1_frac", "l1_miss_rate_Greq_s", "l1_pending_stall_frac", "shader_clock_ghz", "workload", "spp")}
-            pmc["source"] = pj["_file"] + " (earlier rocprofv3 --pmc run, same device sources)"
-            limiter = pj.get("limiter")
-        else:
-            pmc = {"source": None, "note": pmc_source}
-    stream_peak, stream_src = measured_stream_peak()
-    roofline = {
-        "bound": "hbm",  # the roof the contract prices this path against (no dense contraction -> no MFMA roof)
-        "achieved": round(achieved, 2),
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "achieved_is": "ALGORITHMIC bytes (SURVEY 8d: reference-layout record sizes x event counts, cache hits included) / live launch time; NOT HBM utilisation: see hbm_frac",
-        "traffic": traffic,
-        "traffic_source": traffic_source,
-        "hbm_rate": round(traffic / avg_launch_s / 1e9, 2) if traffic else None,
-        "hbm_frac": round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-        "request_rate_Greq_s": round(requests / avg_launch_s / 1e9, 2) if requests else None,
-        "request_roof_Greq_s": request_roof,
-        "request_frac": round(requests / avg_launch_s / 1e9 / request_roof, 4) if requests and request_roof else None,
-        "l1_frac": pmc.get("l1_frac") if pmc else None,  # vector-L1 tag accesses per clock per CU / the measured 0.98 roof (profiles/r02_l1_roof.txt)
-        "limiter": limiter,
-        "pmc": pmc,
-        "peak_measured_read": stream_peak,
-        "peak_measured_source": stream_src,
-        "kernel": "wf_extend<false> (closest hit; primary rays through wf_extend_packet<false> while its packets stay coherent): every closest-hit launch is timed",
-        "kernel_src_sha16": src_hash,
-        "launches_per_step": launches_per_render,
-        "avg_launch_ms": round(avg_launch_s * 1e3, 4),
-        "algorithmic_bytes_per_launch": round(trav_bytes / launches_per_render, 1),
-        "pipeline": {  # all kernels of one rt_render (generate, extend, shade, resolve) against all algorithmic bytes
-            "achieved": round(all_bytes / avg_kernel_s / 1e9, 2),
-            "frac": round(all_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
-            "device_ms_per_step": round(avg_kernel_s * 1e3, 3),
-            "algorithmic_bytes_per_sample": round(all_bytes / (my_pixels * spp), 1),
-            "casts_per_sample": round(cst["casts"] / max(1, cst["samples"]), 3),
-            "nodes_per_cast": round(cst["nodes_visited"] / max(1, cst["casts"]), 1),
-            "tri_tests_per_cast": round(cst["tri_tests"] / max(1, cst["casts"]), 1),
-        },
-    }
+    production = None
+    if extras and args.mode == "parity":
+        production = production_records(scene, wl_name, W, H, spp, full_size, value, None, x_steps, x_warm)
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle
+    if single and not args.no_cpu_baseline:
+        cpu_baseline = cpu_baseline_leg(rt, scene, wl, W, H, args.cpu_seconds)
 
+    extra_workloads = None
+    if extras and args.workload is None and args.mode == "parity" and not (args.width or args.height or args.triangles or args.tex_size or args.spp):
+        del scene
+        xw = WORKLOADS["s10m"]
         t0 = time.time()
-        orc = oracle.OracleScene(scene)
-        t_oracle_build = time.time() - t0
-        cores = effective_cores()
-        # bounded sample of the same workload: every `share`-th 256-pixel span of the same image, reference RNG + libm
-        # (the reference CPU path, raytracer.h:636-662), SPP chosen from a short probe to land near --cpu-seconds.
-        share = wl["cpu_share"] if n_pix >= 256 * wl["cpu_share"] * 4 else 16
-        _, p = orc.run_raytracer(W, H, 1, rng_mode=rt.RT_RNG_REFERENCE, shard_index=0, shard_count=share, shard_block=256, threads=cores)
-        rate = p["samples"] / (p["total_ms"] / 1e3)
-        cpu_spp = int(max(1, min(64, round(args.cpu_seconds * rate / p["samples"]))))
-        _, c = orc.run_raytracer(W, H, cpu_spp, rng_mode=rt.RT_RNG_REFERENCE, shard_index=0, shard_count=share, shard_block=256, threads=cores)
-        cpu_baseline = {
-            "value": round(c["samples"] / (c["total_ms"] / 1e3) / 1e6, 4),
-            "unit": "Msamples/s",
-            "cores": cores,
-            "kind": "port",
-            "sample": (f"same scene, every {share}th 256-pixel span of the {W}x{H} image at {cpu_spp} SPP = {c['samples']} samples, {c['total_ms'] / 1e3:.1f} s, "
-                       f"reference RNG + libm (BVH build {t_oracle_build:.1f} s excluded, as the GPU's is)"),
-        }
-        orc.close()
+        xscene = make_scene(rt, xw, xw["triangles"], xw["tex_size"], 1.0)
+        xt_gen = time.time() - t0
+        xs, xk = max(1, min(args.steps, 3)), 1
+        xr = Runner(rt, torch, dist, xscene, "s10m", "parity", xw["width"], xw["height"], xw["spp_per_gpu"], full_size=True, **common)
+        xv = xr.timed(xs, xk)
+        xrf = xr.roofline()
+        rec = {"metric": xw["metric"], "value": round(xv, 3), "unit": "Msamples/s", "n_gpus": 1, "steps": xs, "warmup": xk, "ms_per_step": round(xr.elapsed / xs * 1e3, 3),
+               "config": {"workload": f"S-10M synthetic (BVH cache stress, BASELINE config 5's scene): {xw['triangles']}+28 triangles, 16x3 {xw['tex_size']}^2 RGBA8 textures, "
+                                      f"{xw['width']}x{xw['height']}, {xw['spp_per_gpu']} SPP, ray_depth 8, device RNG", "workload_id": "s10m", "traversal": MODES["parity"]["text"]},
+               "roofline": xrf, "cpu_baseline": None,
+               "cpu_baseline_skipped": "the oracle's reference-topology build of 10^7 triangles takes ~25 s on this box before a single sample: python bench.py --workload s10m times it",
+               "setup_s": {"scene_generation": round(xt_gen, 2), "rt_create_bvh_upload": round(xr.t_create, 2), "scene_bvh_build": round(xr.build_times["build_ms"] / 1e3, 4)}}
+        xr.close()
+        rec["production"] = production_records(xscene, "s10m", xw["width"], xw["height"], xw["spp_per_gpu"], True, xv, "global", xs, xk)
+        extra_workloads = {"s10m": rec}
 
     if rank == 0:
+        shard_text = "single GPU"
+        if launcher == "torchrun":
+            shard_text = (f"interleaved {SHARD_ROWS}-row tiles over {world} GPU(s), one process per GPU (torch.distributed.run), "
+                          f"{'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal, staged through the host)'} gather of the {'rgb8 image' if film else 'float3 framebuffer'}")
+        elif launcher == "group":
+            shard_text = (f"interleaved {SHARD_ROWS}-row tiles over {args.gpus} GPU(s), ONE process: replicas + ncclCommInitAll inside rt_create_on, "
+                          f"grouped ncclSend/ncclRecv gather of the {'rgb8 image' if film else 'float3 framebuffer'} (csrc/rt_group.cpp)")
         out = {
             "metric": wl["metric"],
             "value": round(value, 3),
             "unit": "Msamples/s",
-            "n_gpus": world,
+            "n_gpus": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{wl['label']} synthetic ({'Sponza-sized' if args.workload == 'sponza' else 'BVH cache stress'}): {n_tri}+28 triangles, 16x3 {tex_size}^2 RGBA8 textures, {W}x{H}, {spp} SPP, ray_depth 8, device RNG",
-                "workload_id": workload_id,
+                "workload": f"{wl['label']} synthetic ({'Sponza-sized' if wl_name == 'sponza' else 'BVH cache stress'}): {n_tri}+28 triangles, 16x3 {tex_size}^2 RGBA8 textures, {W}x{H}, {spp} SPP, ray_depth 8, device RNG",
+                "workload_id": run.workload_id,
+                "baseline_config": ("config 4 (1000 SPP over N GPUs)" if (scaling == "strong" and wl_name == "sponza") else "config 3 shape (64 SPP per GPU)" if wl_name == "sponza" else "config 5 shape (32 SPP per GPU)"),
                 "width": W,
                 "height": H,
                 "spp": spp,
-                "triangles": int(scene.n_triangles),
-                "sharding": f"interleaved {SHARD_ROWS}-row tiles over {world} GPU(s), RCCL gather of the {'rgb8 image' if film else 'float3 framebuffer'}" if world > 1 else "single GPU",
+                "triangles": int(n_tri + 28),
+                "sharding": shard_text,
+                "launcher": launcher,
+                "ranks_formed": run.ranks_formed,
                 "film": "device (rt_render_rgb8)" if film else "none (linear float3)",
-                "traversal": "8-wide quantised BVH, global-best culling, octant order (production)" if args.wide else "global-best pruning (production)" if gbest else "reference order and pruning (parity mode)",
-                "bvh": "reference topology, host build (parity mode)" if args.bvh == "reference" else "LBVH built on the device (production mode: identical closest hits, different topology and counters)",
+                "traversal": MODES[args.mode]["text"],
+                "bvh": "reference topology, host build" if args.bvh == "reference" else "LBVH built on the device (identical closest hits, different topology and counters)",
             },
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
-            "setup_s": {"scene_generation": round(t_gen, 2), "rt_create_bvh_upload": round(t_create, 2), "scene_bvh_build": round(build_times["build_ms"] / 1e3, 4)},
+            "production": production,
+            "extra_workloads": extra_workloads,
+            "setup_s": setup,
         }
         print(json.dumps(out), flush=True)
-    dev.close()
-    if world > 1:
+    if launcher == "torchrun":
         dist.destroy_process_group()
 
 

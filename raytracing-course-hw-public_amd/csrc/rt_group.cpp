@@ -36,6 +36,7 @@ struct Rccl {
     void *handle = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -65,6 +66,7 @@ Rccl &rccl() {
         };
         r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
         r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
         r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
@@ -112,6 +114,7 @@ struct Group {
     bool self_exchange = false; // RT_GROUP_SELF_EXCHANGE=1: rank 0's own blocks also travel through ncclSend/ncclRecv (N = 1 test)
     char *recv = nullptr;       // on ranks[0].device: the other ranks' slabs
     size_t recv_cap = 0;
+    bool comm_broken = false;   // an exchange failed and the communicators were aborted: later renders report RT_ERR_COMM at once
 };
 
 namespace {
@@ -193,14 +196,20 @@ int group_create(const rt_scene_desc *desc, const int *devices, int n_devices, G
     const char *se = std::getenv("RT_GROUP_SELF_EXCHANGE");
     g->self_exchange = se && std::atoi(se) != 0;
     g->ranks.resize(n_devices);
-    // replicas: every GPU builds / uploads its own copy of the scene (C5: 2.4 GB of 288 GB), one host thread per GPU
+    // The host half of rt_create (both reference-topology BVH builds, flattening / wide collapse, shading records, texture pool)
+    // is done ONCE; every GPU then uploads the same arrays, one host thread per GPU (C5: 2.4 GB of 288 GB per replica).
+    std::shared_ptr<const PreparedScene> prep;
+    if (int rc = prepare(desc, &prep); rc != RT_OK) {
+        delete g;
+        return rc;
+    }
     std::vector<int> rcs(n_devices, RT_OK);
     std::vector<std::string> errs(n_devices);
     std::vector<std::thread> th;
     for (int i = 0; i < n_devices; ++i) {
         g->ranks[i].device = devices[i];
         th.emplace_back([&, i] {
-            rcs[i] = rt_create(desc, devices[i], &g->ranks[i].scene);
+            rcs[i] = create_replica(desc, prep, devices[i], &g->ranks[i].scene);
             if (rcs[i] != RT_OK)
                 errs[i] = rt_last_error();
             else if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&g->ranks[i].stream, hipStreamNonBlocking) != hipSuccess) {
@@ -316,6 +325,27 @@ int group_render(Group *g, const rt_params *p, float *fb, uint8_t *rgb8, rt_stat
             return fail(rcs[r], "GPU " + std::to_string(g->ranks[r].device) + ": " + errs[r]);
 
     // ---- phase 2: gather on rank 0. Every rank packs and sends on its own stream; rank 0 posts all receives in one group.
+    // Nobody may be left waiting: (1) whether the exchange happens at all is decided BEFORE the threads start (a rank that
+    // cannot even select its device would never post its send); (2) a rank whose RCCL call fails aborts EVERY communicator of
+    // the group (ncclCommAbort), which completes the peers' pending operations with an error instead of letting their
+    // hipStreamSynchronize wait for a transfer that will never be matched; the group is unusable afterwards (RT_ERR_COMM).
+    if (g->use_rccl && g->comm_broken)
+        return fail(RT_ERR_COMM, "rt group: the communicator was aborted by an earlier failed exchange; create the scene again");
+    for (uint32_t r = 0; r < G; ++r)
+        if (hipError_t e = hipSetDevice(g->ranks[r].device); e != hipSuccess)
+            return hip_fail("rt group: hipSetDevice before the exchange", e);
+    std::mutex abort_mutex;
+    auto abort_all = [&]() {
+        std::lock_guard<std::mutex> lock(abort_mutex);
+        if (g->comm_broken || !rccl().CommAbort)
+            return;
+        g->comm_broken = true;
+        for (Replica &R : g->ranks)
+            if (R.comm) {
+                (void)rccl().CommAbort(R.comm);
+                R.comm = nullptr;
+            }
+    };
     {
         std::vector<std::thread> th;
         for (uint32_t r = 0; r < G; ++r)
@@ -329,15 +359,19 @@ int group_render(Group *g, const rt_params *p, float *fb, uint8_t *rgb8, rt_stat
                     }
                     return e == hipSuccess;
                 };
+                bool comm_failed = false;
                 auto nccl_try = [&](ncclResult_t e, const char *what) {
-                    if (e != ncclSuccess && rcs[r] == RT_OK) {
-                        rcs[r] = RT_ERR_COMM;
-                        errs[r] = std::string(what) + ": " + N.GetErrorString(e);
+                    if (e != ncclSuccess) {
+                        comm_failed = true;
+                        if (rcs[r] == RT_OK) {
+                            rcs[r] = RT_ERR_COMM;
+                            errs[r] = std::string(what) + ": " + N.GetErrorString(e);
+                        }
                     }
                     return e == ncclSuccess;
                 };
-                if (!hip_try(hipSetDevice(R.device), "hipSetDevice"))
-                    return;
+                ncclComm_t comm = R.comm; // abort_all() of another rank may clear R.comm: use the copy taken now
+                (void)hip_try(hipSetDevice(R.device), "hipSetDevice"); // verified for every rank just above; the exchange is posted regardless
                 const bool sends = r > 0 || exchange0;
                 const size_t bytes = blk[r].pixels(block) * es;
                 if (sends && bytes)
@@ -347,16 +381,19 @@ int group_render(Group *g, const rt_params *p, float *fb, uint8_t *rgb8, rt_stat
                     if (r == 0) {
                         nccl_try(N.GroupStart(), "ncclGroupStart");
                         if (exchange0 && bytes)
-                            nccl_try(N.Send(R.slab, bytes, ncclUint8, 0, R.comm, R.stream), "ncclSend");
+                            nccl_try(N.Send(R.slab, bytes, ncclUint8, 0, comm, R.stream), "ncclSend");
                         for (uint32_t q = exchange0 ? 0 : 1; q < G; ++q)
                             if (const size_t qb = blk[q].pixels(block) * es)
-                                nccl_try(N.Recv(g->recv + recv_off[q], qb, ncclUint8, (int)q, R.comm, R.stream), "ncclRecv");
+                                nccl_try(N.Recv(g->recv + recv_off[q], qb, ncclUint8, (int)q, comm, R.stream), "ncclRecv");
                         nccl_try(N.GroupEnd(), "ncclGroupEnd");
                     } else if (bytes) {
-                        nccl_try(N.Send(R.slab, bytes, ncclUint8, 0, R.comm, R.stream), "ncclSend");
+                        nccl_try(N.Send(R.slab, bytes, ncclUint8, 0, comm, R.stream), "ncclSend");
                     }
+                    if (comm_failed)
+                        abort_all(); // the peers' matching operations would never complete
                 }
-                hip_try(hipStreamSynchronize(R.stream), "gather stream");
+                if (!hip_try(hipStreamSynchronize(R.stream), "gather stream") && g->use_rccl)
+                    abort_all();
             });
         for (auto &t : th)
             t.join();

@@ -7,14 +7,20 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 
 #include "../../include/rt_abi.h"
 
 namespace rt {
 
 struct Group;
+struct PreparedScene; // rt_scene.cpp: the host half of rt_create (BVH builds, texture pool, ...), shared by all replicas
 
-// `devices` = HIP ordinals (n_devices >= 1). Creates one single-device scene per entry through rt_create and one RCCL
+// rt_scene.cpp: build the host half once / put one replica of it on a device
+int prepare(const rt_scene_desc *desc, std::shared_ptr<const PreparedScene> *out);
+int create_replica(const rt_scene_desc *desc, const std::shared_ptr<const PreparedScene> &prep, int device, rt_scene **out);
+
+// `devices` = HIP ordinals (n_devices >= 1). Prepares the scene once on the host, puts one replica on every entry and creates one RCCL
 // communicator over them (ncclCommInitAll). RT_ERR_COMM when RCCL is missing or refuses the device set.
 int group_create(const rt_scene_desc *desc, const int *devices, int n_devices, Group **out);
 void group_destroy(Group *g);

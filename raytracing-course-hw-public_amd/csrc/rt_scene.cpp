@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <future>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -74,6 +75,10 @@ inline float len_h(V3h a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
 
 } // namespace
 
+namespace rt {
+struct PreparedScene;
+}
+
 struct rt_scene {
     rt::Group *group = nullptr; // multi-GPU scene: replicas + RCCL communicator (rt_group.cpp); the fields below stay unused
     int device = 0;
@@ -83,8 +88,9 @@ struct rt_scene {
     DevScene dev{};
     rt_camera cam{};
     std::vector<void *> owned;
-    rt::HostBvh host_bvh[2];
-    bool device_built = false; // scene BVH built by rt_bvh_device.hip: host_bvh[0] is reconstructed from HBM on demand
+    std::shared_ptr<const rt::PreparedScene> prep; // the host half of rt_create, shared by the replicas of a multi-GPU scene
+    rt::HostBvh rebuilt_bvh;   // device-built scene BVH: the reference-style node list, reconstructed from HBM on demand
+    bool device_built = false; // scene BVH built by rt_bvh_device.hip
     bool wide_built = false;   // RT_BUILD_WIDE: the scene BVH in HBM is the 8-wide quantised tree (wide_build.cpp); host_bvh[0] is the
                                // binary tree it was collapsed from when that one was built on the host
     uint32_t wide_depth = 0;
@@ -271,21 +277,67 @@ static uint32_t light_lds_inner(const rt::FlatBvh &f) {
     return (uint32_t)f.nodes.size() + 1u;
 }
 
-static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return rt::fail(RT_ERR_NO_DEVICE, "rt_create: no HIP device available (this library has no CPU fallback)");
-    if (device < 0 || device >= ndev)
-        return rt::fail(RT_ERR_INVALID_ARG, "rt_create: device ordinal out of range");
-    s->device = device;
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    s->num_cus = prop.multiProcessorCount;
-    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&s->ev0));
-    HIP_TRY(hipEventCreate(&s->ev1));
+// ---------------------------------------------------------------------------------------------- rt_create, host half
+// Everything rt_create derives from the descriptor WITHOUT a device: both reference-topology BVH builds and their flattening
+// (or the wide collapse), shading records, materials, the tiled / interleaved texture pool, tables. Built ONCE per rt_create /
+// rt_create_on and uploaded to every GPU of a group (a multi-GPU scene used to repeat all of it per GPU: an 8.5 s
+// single-thread build times eight on S-10M).
+namespace rt {
+struct PreparedScene {
+    bool dev_build = false, wide_build = false;
+    HostBvh host_bvh[2];
+    FlatBvh flat[2];            // [0] empty when the scene BVH is built on the device or is wide
+    WideBvh wide;               // wide_build && !dev_build
+    std::vector<DevTri> wide_tris;
+    std::vector<DevAttr> attrs; // scene-BVH order (empty when built on the device)
+    std::vector<DevLightAux> laux;
+    std::vector<DevMaterial> mats;
+    std::vector<DevTexture> texs;
+    std::vector<uint32_t> pool;
+    std::vector<rt_primitive_desc> prims;
+    std::vector<float> lut_lin, lut_gam;
+    double build_ms = 0, wide_ms = 0;
+    float wide_cost_node = 1.0f, wide_cost_tri = 0.3f;
+};
+} // namespace rt
 
+// shading records in the order of the triangle records `tris` (to_intersection_info's inputs, bvh.h:80-121)
+static void make_attrs(const rt_scene_desc *d, const std::vector<DevTri> &tris, std::vector<DevAttr> &attrs) {
+    attrs.resize(tris.size());
+    for (size_t k = 0; k < attrs.size(); ++k) {
+        const uint32_t t = tris[k].prim;
+        DevAttr &a = attrs[k];
+        std::memset(&a, 0, sizeof(a));
+        std::memcpy(a.n, d->normals + 9 * (size_t)t, 36);
+        std::memcpy(a.tg, d->tangents + 9 * (size_t)t, 36);
+        std::memcpy(a.uv, d->texcoords + 6 * (size_t)t, 24);
+        const DevTri &tr = tris[k];
+        V3h c = cross_h({tr.v[0], tr.v[1], tr.v[2]}, {tr.u[0], tr.u[1], tr.u[2]}); // triangle::normal geometry.h:477-479
+        float l = len_h(c);
+        a.gn[0] = c.x / l;
+        a.gn[1] = c.y / l;
+        a.gn[2] = c.z / l;
+        a.material = d->material_ids[t];
+    }
+}
+// triangle records of the wide tree: the reference's operands a, b - a, c - a (geometry.h:473-475) in the tree's own order
+static void make_wide_tris(const rt_scene_desc *d, const rt::WideBvh &wide, std::vector<DevTri> &tris) {
+    tris.resize(wide.order.size());
+    for (size_t k = 0; k < tris.size(); ++k) {
+        const float *p = d->positions + 9 * (size_t)wide.order[k];
+        DevTri &t = tris[k];
+        for (int c = 0; c < 3; ++c) {
+            t.a[c] = p[c];
+            t.v[c] = p[3 + c] - p[c];
+            t.u[c] = p[6 + c] - p[c];
+        }
+        t.prim = wide.order[k];
+        t.flags = 0;
+        t.pad = 0;
+    }
+}
+
+static int prepare_scene(const rt_scene_desc *d, rt::PreparedScene &P) {
     const uint32_t n = d->n_triangles;
     for (uint32_t i = 0; i < n; ++i)
         if (d->material_ids[i] >= d->n_materials)
@@ -296,6 +348,9 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
         if (!tex_ok(m.color_tex) || !tex_ok(m.emissive_tex) || !tex_ok(m.metallic_roughness_tex) || !tex_ok(m.normal_tex))
             return rt::fail(RT_ERR_INVALID_ARG, "rt_create: texture index out of range");
     }
+    for (uint32_t i = 0; i < d->n_textures; ++i)
+        if (d->textures[i].width == 0 || d->textures[i].height == 0 || !d->textures[i].rgba8)
+            return rt::fail(RT_ERR_INVALID_ARG, "rt_create: empty texture");
 
     // ---- RaytracerStaticContext: scene_bvh over everything, light_bvh over emission != 0 (raytracer.h:441-447)
     std::vector<uint32_t> all(n), lights;
@@ -306,121 +361,55 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
             lights.push_back(i);
     }
     const char *env_dev = std::getenv("RT_BVH_DEVICE"), *env_wide = std::getenv("RT_BVH_WIDE");
-    const bool dev_build = n > 0 && ((d->build_flags & RT_BUILD_DEVICE_LBVH) || (env_dev && std::atoi(env_dev) != 0));
-    const bool wide_build = n > 0 && ((d->build_flags & RT_BUILD_WIDE) || (env_wide && std::atoi(env_wide) != 0));
-    rt::FlatBvh flat[2];
-    rt::DeviceBvh dbvh{};
-    rt::WideBvh wide;
-    std::vector<DevTri> wide_tris;
-    std::vector<DevAttr> attrs;
-    // shading records in the order of the triangle records `tris` (to_intersection_info's inputs, bvh.h:80-121)
-    auto make_attrs = [&](const std::vector<DevTri> &tris) {
-        attrs.resize(tris.size());
-        for (size_t k = 0; k < attrs.size(); ++k) {
-            const uint32_t t = tris[k].prim;
-            DevAttr &a = attrs[k];
-            std::memset(&a, 0, sizeof(a));
-            std::memcpy(a.n, d->normals + 9 * (size_t)t, 36);
-            std::memcpy(a.tg, d->tangents + 9 * (size_t)t, 36);
-            std::memcpy(a.uv, d->texcoords + 6 * (size_t)t, 24);
-            const DevTri &tr = tris[k];
-            V3h c = cross_h({tr.v[0], tr.v[1], tr.v[2]}, {tr.u[0], tr.u[1], tr.u[2]}); // triangle::normal geometry.h:477-479
-            float l = len_h(c);
-            a.gn[0] = c.x / l;
-            a.gn[1] = c.y / l;
-            a.gn[2] = c.z / l;
-            a.material = d->material_ids[t];
-        }
-    };
-    // The geometry half of rt_create — both BVH builds, flattening, shading records — runs on a thread of its own while
-    // this thread lays out the texture pool below (SURVEY 8f-2 "overlap"): on S-sponza the two halves take about as long
-    // as each other (BVH 0.10 s, 268 MB of tiled / interleaved texels 0.2 s).
-    auto geometry_task = std::async(std::launch::async, [&]() -> std::pair<int, std::string> {
+    P.dev_build = n > 0 && ((d->build_flags & RT_BUILD_DEVICE_LBVH) || (env_dev && std::atoi(env_dev) != 0));
+    P.wide_build = n > 0 && ((d->build_flags & RT_BUILD_WIDE) || (env_wide && std::atoi(env_wide) != 0));
+    if (const char *e = std::getenv("RT_WIDE_COST_NODE"))
+        P.wide_cost_node = (float)std::atof(e);
+    if (const char *e = std::getenv("RT_WIDE_COST_TRI"))
+        P.wide_cost_tri = (float)std::atof(e);
+    // The geometry half — both BVH builds, flattening or the wide collapse, shading records — runs on a thread of its own while
+    // this thread lays out the texture pool below (SURVEY 8f-2 "overlap"): on S-sponza the two halves take about as long as
+    // each other (BVH 0.10 s, 268 MB of tiled / interleaved texels 0.2 s).
+    auto geometry_task = std::async(std::launch::async, [&]() {
         const auto tb0 = std::chrono::steady_clock::now();
-        if (dev_build) {
-            if (hipError_t de = hipSetDevice(device); de != hipSuccess)
-                return std::make_pair((int)RT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(de));
-            // ---- production mode: the scene BVH, the triangle records and the shading records are built on the device
-            const char *what = "";
-            hipError_t be = rt::build_bvh_device(d, s->stream, &dbvh, &what);
-            if (be != hipSuccess)
-                return std::make_pair(be == hipErrorOutOfMemory ? (int)RT_ERR_OOM : (int)RT_ERR_HIP, std::string("device BVH build: ") + what + ": " + hipGetErrorString(be));
-            s->device_built = true;
-            s->build_ms = dbvh.build_ms;
-            s->build_upload_ms = dbvh.upload_ms;
-            if (!wide_build) {
-                s->owned.push_back(dbvh.nodes);
-                s->owned.push_back(dbvh.tris);
-                s->owned.push_back(dbvh.attrs);
+        if (!P.dev_build) {
+            P.host_bvh[0] = rt::build_bvh(d->positions, n, all);
+            if (!P.wide_build) {
+                P.flat[0] = rt::flatten_bvh(P.host_bvh[0], d->positions);
+                make_attrs(d, P.flat[0].tris, P.attrs);
             }
-        } else {
-            s->host_bvh[0] = rt::build_bvh(d->positions, n, all);
-            if (!wide_build) {
-                flat[0] = rt::flatten_bvh(s->host_bvh[0], d->positions);
-                make_attrs(flat[0].tris);
+            P.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
+            if (P.wide_build) { // production build: collapse the reference-topology tree into the 8-wide quantised tree
+                const auto tw0 = std::chrono::steady_clock::now();
+                P.wide = rt::build_wide(rt::bin_from_host(P.host_bvh[0]), d->positions, P.wide_cost_node, P.wide_cost_tri);
+                make_wide_tris(d, P.wide, P.wide_tris);
+                make_attrs(d, P.wide_tris, P.attrs);
+                P.wide_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
             }
-            s->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
         }
-        if (wide_build) {
-            // ---- production build: collapse the binary tree (reference topology, or the LBVH read back from HBM) into the
-            // 8-wide quantised tree; triangle and shading records follow the wide tree's own order
-            const auto tw0 = std::chrono::steady_clock::now();
-            rt::BinBvh bin;
-            if (dev_build) {
-                std::vector<DevNode> hn(dbvh.n_inner);
-                std::vector<DevTri> ht(dbvh.n_tris);
-                hipError_t ce = hipSuccess;
-                if (dbvh.n_inner)
-                    ce = hipMemcpy(hn.data(), dbvh.nodes, sizeof(DevNode) * hn.size(), hipMemcpyDeviceToHost);
-                if (ce == hipSuccess && dbvh.n_tris)
-                    ce = hipMemcpy(ht.data(), dbvh.tris, sizeof(DevTri) * ht.size(), hipMemcpyDeviceToHost);
-                (void)hipFree(dbvh.nodes);
-                (void)hipFree(dbvh.tris);
-                (void)hipFree(dbvh.attrs);
-                if (ce != hipSuccess)
-                    return std::make_pair((int)RT_ERR_HIP, std::string("wide build: reading the device BVH back: ") + hipGetErrorString(ce));
-                bin = rt::bin_from_device(hn, ht, dbvh.root);
-                dbvh.nodes = nullptr, dbvh.tris = nullptr, dbvh.attrs = nullptr;
-            } else {
-                bin = rt::bin_from_host(s->host_bvh[0]);
-            }
-            float cn = 1.0f, ct = 0.3f;
-            if (const char *e = std::getenv("RT_WIDE_COST_NODE"))
-                cn = (float)std::atof(e);
-            if (const char *e = std::getenv("RT_WIDE_COST_TRI"))
-                ct = (float)std::atof(e);
-            wide = rt::build_wide(bin, d->positions, cn, ct);
-            wide_tris.resize(wide.order.size());
-            for (size_t k = 0; k < wide_tris.size(); ++k) {
-                const float *p = d->positions + 9 * (size_t)wide.order[k];
-                DevTri &t = wide_tris[k];
-                for (int c = 0; c < 3; ++c) {
-                    t.a[c] = p[c];
-                    t.v[c] = p[3 + c] - p[c]; // triangle::v geometry.h:473
-                    t.u[c] = p[6 + c] - p[c]; // triangle::u geometry.h:475
-                }
-                t.prim = wide.order[k];
-                t.flags = 0;
-                t.pad = 0;
-            }
-            make_attrs(wide_tris);
-            s->wide_built = true;
-            s->wide_depth = wide.depth;
-            s->wide_cost = wide.sah_cost;
-            s->wide_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+        P.host_bvh[1] = rt::build_bvh(d->positions, n, lights);
+        P.flat[1] = rt::flatten_bvh(P.host_bvh[1], d->positions);
+        P.laux.resize(P.flat[1].tris.size());
+        for (size_t k = 0; k < P.laux.size(); ++k) {
+            const DevTri &tr = P.flat[1].tris[k];
+            V3h c = cross_h({tr.v[0], tr.v[1], tr.v[2]}, {tr.u[0], tr.u[1], tr.u[2]});
+            float l = len_h(c);
+            P.laux[k].normal[0] = c.x / l;
+            P.laux[k].normal[1] = c.y / l;
+            P.laux[k].normal[2] = c.z / l;
+            P.laux[k].area = l / 2; // triangle::square geometry.h:481-483
         }
-        s->host_bvh[1] = rt::build_bvh(d->positions, n, lights);
-        flat[1] = rt::flatten_bvh(s->host_bvh[1], d->positions);
-    return std::make_pair((int)RT_OK, std::string());
     });
-    struct JoinGeometry { // every early return below must wait for the task: it works on locals of this frame
-        std::future<std::pair<int, std::string>> &f;
+    struct JoinGeometry { // every return below must wait for the task: it works on `P` and on locals of this frame
+        std::future<void> &f;
         ~JoinGeometry() {
             if (f.valid())
                 f.wait();
         }
     } join_geometry{geometry_task};
-    std::vector<DevMaterial> mats(d->n_materials);
+
+    std::vector<DevMaterial> &mats = P.mats;
+    mats.resize(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const rt_material_desc &m = d->materials[i];
         DevMaterial &o = mats[i];
@@ -437,11 +426,8 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
     }
     // ---- texture views (rt_device_types.h DevTexture): tiled storage; textures one material samples together at equal
     // size are interleaved record by record. A material slot refers to a VIEW, so materials are remapped here.
-    for (uint32_t i = 0; i < d->n_textures; ++i)
-        if (d->textures[i].width == 0 || d->textures[i].height == 0 || !d->textures[i].rgba8)
-            return rt::fail(RT_ERR_INVALID_ARG, "rt_create: empty texture");
-    std::vector<DevTexture> texs;
-    std::vector<uint32_t> pool;
+    std::vector<DevTexture> &texs = P.texs;
+    std::vector<uint32_t> &pool = P.pool;
     {
         auto store = [&](const std::vector<int32_t> &members, uint32_t stride, std::vector<int32_t> &view_of_member) {
             // members: texture ids of equal size (or -1 for an unused slot), one per record dword; returns view ids
@@ -529,49 +515,108 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
             return rt::fail(RT_ERR_OOM, "rt_create: texture pool exceeds 2^32 texels");
     }
     // ---- analytic primitives of the scene-txt front end (rt_primspec.h)
-    std::vector<rt_primitive_desc> prims;
     if (d->n_primitives) {
         if (!d->primitives || d->n_primitives > RT_MAX_PRIMITIVES)
             return rt::fail(RT_ERR_INVALID_ARG, "rt_create: bad primitive list (limit " + std::to_string(RT_MAX_PRIMITIVES) + ")");
-        prims.assign(d->primitives, d->primitives + d->n_primitives);
-        for (const rt_primitive_desc &pr : prims)
+        P.prims.assign(d->primitives, d->primitives + d->n_primitives);
+        for (const rt_primitive_desc &pr : P.prims)
             if ((pr.kind != RT_PRIM_ELLIPSOID && pr.kind != RT_PRIM_PLANE) || pr.material_id >= d->n_materials)
                 return rt::fail(RT_ERR_INVALID_ARG, "rt_create: primitive with unknown kind or material id out of range");
     }
-    std::vector<float> lut_lin(256), lut_gam(256);
+    P.lut_lin.resize(256);
+    P.lut_gam.resize(256);
     for (int k = 0; k < 256; ++k) {
-        lut_lin[k] = k / 255.0f;               // Texture::load_img geometry.h:593-594
-        lut_gam[k] = std::pow(lut_lin[k], 2.2f); // rgba_apply_gamma geometry.h:525-527 (float powf)
+        P.lut_lin[k] = k / 255.0f;                 // Texture::load_img geometry.h:593-594
+        P.lut_gam[k] = std::pow(P.lut_lin[k], 2.2f); // rgba_apply_gamma geometry.h:525-527 (float powf)
     }
+    geometry_task.get();
+    return RT_OK;
+}
 
-    {
-        const std::pair<int, std::string> gr = geometry_task.get();
-        if (gr.first != RT_OK)
-            return rt::fail(gr.first, gr.second);
+// ---------------------------------------------------------------------------------------------- rt_create, device half
+static int create_impl(const rt_scene_desc *d, const std::shared_ptr<const rt::PreparedScene> &prep, int device, rt_scene *s) {
+    const rt::PreparedScene &P = *prep;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return rt::fail(RT_ERR_NO_DEVICE, "rt_create: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_create: device ordinal out of range");
+    s->device = device;
+    s->prep = prep;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    s->num_cus = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+
+    const uint32_t n = d->n_triangles;
+    const bool dev_build = P.dev_build, wide_build = P.wide_build;
+    rt::DeviceBvh dbvh{};
+    // a wide tree collapsed from the DEVICE-built binary tree belongs to this GPU's build (the host-built one is in `P`)
+    rt::WideBvh wide_local;
+    std::vector<DevTri> wide_tris_local;
+    std::vector<DevAttr> attrs_local;
+    const rt::WideBvh *wide = &P.wide;
+    const std::vector<DevTri> *wide_tris = &P.wide_tris;
+    const std::vector<DevAttr> *attrs = &P.attrs;
+    s->build_ms = P.build_ms;
+    s->wide_ms = P.wide_ms;
+    if (dev_build) {
+        // ---- the scene BVH, the triangle records and the shading records are built on the device (rt_bvh_device.hip)
+        const char *what = "";
+        hipError_t be = rt::build_bvh_device(d, s->stream, &dbvh, &what);
+        if (be != hipSuccess)
+            return rt::fail(be == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string("device BVH build: ") + what + ": " + hipGetErrorString(be));
+        s->device_built = true;
+        s->build_ms = dbvh.build_ms;
+        s->build_upload_ms = dbvh.upload_ms;
+        if (!wide_build) {
+            s->owned.push_back(dbvh.nodes);
+            s->owned.push_back(dbvh.tris);
+            s->owned.push_back(dbvh.attrs);
+        } else {
+            // production build on top of the device tree: read it back, collapse on the host, upload the wide tree
+            const auto tw0 = std::chrono::steady_clock::now();
+            std::vector<DevNode> hn(dbvh.n_inner);
+            std::vector<DevTri> ht(dbvh.n_tris);
+            hipError_t ce = hipSuccess;
+            if (dbvh.n_inner)
+                ce = hipMemcpy(hn.data(), dbvh.nodes, sizeof(DevNode) * hn.size(), hipMemcpyDeviceToHost);
+            if (ce == hipSuccess && dbvh.n_tris)
+                ce = hipMemcpy(ht.data(), dbvh.tris, sizeof(DevTri) * ht.size(), hipMemcpyDeviceToHost);
+            (void)hipFree(dbvh.nodes);
+            (void)hipFree(dbvh.tris);
+            (void)hipFree(dbvh.attrs);
+            dbvh.nodes = nullptr, dbvh.tris = nullptr, dbvh.attrs = nullptr;
+            if (ce != hipSuccess)
+                return rt::fail(RT_ERR_HIP, std::string("wide build: reading the device BVH back: ") + hipGetErrorString(ce));
+            wide_local = rt::build_wide(rt::bin_from_device(hn, ht, dbvh.root), d->positions, P.wide_cost_node, P.wide_cost_tri);
+            make_wide_tris(d, wide_local, wide_tris_local);
+            make_attrs(d, wide_tris_local, attrs_local);
+            wide = &wide_local, wide_tris = &wide_tris_local, attrs = &attrs_local;
+            s->wide_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+        }
     }
-    std::vector<DevLightAux> laux(flat[1].tris.size());
-    for (size_t k = 0; k < laux.size(); ++k) {
-        const DevTri &tr = flat[1].tris[k];
-        V3h c = cross_h({tr.v[0], tr.v[1], tr.v[2]}, {tr.u[0], tr.u[1], tr.u[2]});
-        float l = len_h(c);
-        laux[k].normal[0] = c.x / l;
-        laux[k].normal[1] = c.y / l;
-        laux[k].normal[2] = c.z / l;
-        laux[k].area = l / 2; // triangle::square geometry.h:481-483
+    if (wide_build) {
+        s->wide_built = true;
+        s->wide_depth = wide->depth;
+        s->wide_cost = wide->sah_cost;
     }
     DevScene &D = s->dev;
     int rc;
     for (int w = 0; w < 2; ++w) {
         DevBvh &b = w == 0 ? D.scene : D.lights;
         if (w == 0 && wide_build) {
-            if ((rc = upload(wide.nodes, &b.wide, s->owned)) != RT_OK)
+            if ((rc = upload(wide->nodes, &b.wide, s->owned)) != RT_OK)
                 return rc;
-            if ((rc = upload(wide_tris, &b.tris, s->owned)) != RT_OK)
+            if ((rc = upload(*wide_tris, &b.tris, s->owned)) != RT_OK)
                 return rc;
             b.nodes = nullptr;
-            b.root = wide.nodes.empty() ? RT_NONE : 0u;
-            b.n_tris = (uint32_t)wide_tris.size();
-            b.n_wide = (uint32_t)wide.nodes.size();
+            b.root = wide->nodes.empty() ? RT_NONE : 0u;
+            b.n_tris = (uint32_t)wide_tris->size();
+            b.n_wide = (uint32_t)wide->nodes.size();
             b.fast_ok = 0u;
             s->dev_n_inner[0] = 0;
             continue;
@@ -585,35 +630,35 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
             s->dev_n_inner[0] = dbvh.n_inner;
             continue;
         }
-        if ((rc = upload(flat[w].nodes, &b.nodes, s->owned)) != RT_OK)
+        if ((rc = upload(P.flat[w].nodes, &b.nodes, s->owned)) != RT_OK)
             return rc;
-        if ((rc = upload(flat[w].tris, &b.tris, s->owned)) != RT_OK)
+        if ((rc = upload(P.flat[w].tris, &b.tris, s->owned)) != RT_OK)
             return rc;
-        b.root = flat[w].root;
-        b.n_tris = (uint32_t)flat[w].tris.size();
-        b.fast_ok = flat[w].fast_ok ? 1u : 0u;
-        b.lds_inner = w == 1 ? light_lds_inner(flat[w]) : 0u;
-        s->dev_n_inner[w] = (uint32_t)flat[w].nodes.size();
+        b.root = P.flat[w].root;
+        b.n_tris = (uint32_t)P.flat[w].tris.size();
+        b.fast_ok = P.flat[w].fast_ok ? 1u : 0u;
+        b.lds_inner = w == 1 ? light_lds_inner(P.flat[w]) : 0u;
+        s->dev_n_inner[w] = (uint32_t)P.flat[w].nodes.size();
     }
     if (dev_build && !wide_build)
         D.attrs = dbvh.attrs;
-    else if ((rc = upload(attrs, &D.attrs, s->owned)) != RT_OK)
+    else if ((rc = upload(*attrs, &D.attrs, s->owned)) != RT_OK)
         return rc;
-    if ((rc = upload(laux, &D.light_aux, s->owned)) != RT_OK)
+    if ((rc = upload(P.laux, &D.light_aux, s->owned)) != RT_OK)
         return rc;
-    if ((rc = upload(mats, &D.materials, s->owned)) != RT_OK)
+    if ((rc = upload(P.mats, &D.materials, s->owned)) != RT_OK)
         return rc;
-    if ((rc = upload(texs, &D.textures, s->owned)) != RT_OK)
+    if ((rc = upload(P.texs, &D.textures, s->owned)) != RT_OK)
         return rc;
-    if ((rc = upload(pool, &D.texels, s->owned)) != RT_OK)
+    if ((rc = upload(P.pool, &D.texels, s->owned)) != RT_OK)
         return rc;
-    if ((rc = upload(lut_lin, &D.lut_linear, s->owned)) != RT_OK)
+    if ((rc = upload(P.lut_lin, &D.lut_linear, s->owned)) != RT_OK)
         return rc;
-    if ((rc = upload(lut_gam, &D.lut_gamma, s->owned)) != RT_OK)
+    if ((rc = upload(P.lut_gam, &D.lut_gamma, s->owned)) != RT_OK)
         return rc;
-    if ((rc = upload(prims, &D.prims, s->owned)) != RT_OK)
+    if ((rc = upload(P.prims, &D.prims, s->owned)) != RT_OK)
         return rc;
-    D.n_prims = (uint32_t)prims.size();
+    D.n_prims = (uint32_t)P.prims.size();
     D.n_triangles = n;
     std::memcpy(D.cam_pos, d->camera.position, 12);
     std::memcpy(D.cam_right, d->camera.right, 12);
@@ -626,9 +671,9 @@ static int create_impl(const rt_scene_desc *d, int device, rt_scene *s) {
         if (dev_build) {
             lo = dbvh.lo[k];
             hi = dbvh.hi[k];
-        } else if (s->host_bvh[0].root != RT_NONE && !s->host_bvh[0].nodes.empty()) {
-            lo = s->host_bvh[0].nodes[s->host_bvh[0].root].lo[k];
-            hi = s->host_bvh[0].nodes[s->host_bvh[0].root].hi[k];
+        } else if (P.host_bvh[0].root != RT_NONE && !P.host_bvh[0].nodes.empty()) {
+            lo = P.host_bvh[0].nodes[P.host_bvh[0].root].lo[k];
+            hi = P.host_bvh[0].nodes[P.host_bvh[0].root].hi[k];
         }
         D.bounds_lo[k] = lo;
         D.bounds_inv[k] = (hi > lo) ? 1.0f / (hi - lo) : 0.0f;
@@ -662,6 +707,25 @@ static int check_desc(const rt_scene_desc *desc, const void *out) {
     return RT_OK;
 }
 
+// one replica of a prepared scene on one device (rt_group.cpp builds a multi-GPU scene out of these)
+int rt::create_replica(const rt_scene_desc *desc, const std::shared_ptr<const rt::PreparedScene> &prep, int device, rt_scene **out) {
+    rt_scene *s = new rt_scene();
+    int rc = create_impl(desc, prep, device, s);
+    if (rc != RT_OK) {
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return RT_OK;
+}
+int rt::prepare(const rt_scene_desc *desc, std::shared_ptr<const rt::PreparedScene> *out) {
+    auto P = std::make_shared<rt::PreparedScene>();
+    if (int rc = prepare_scene(desc, *P); rc != RT_OK)
+        return rc;
+    *out = P;
+    return RT_OK;
+}
+
 extern "C" int rt_create_on(const rt_scene_desc *desc, const int *devices, int n_devices, rt_scene **out) {
     if (int rc = check_desc(desc, out); rc != RT_OK)
         return rc;
@@ -689,14 +753,13 @@ extern "C" int rt_create(const rt_scene_desc *desc, int device, rt_scene **out) 
             all[i] = i;
         return rt_create_on(desc, all.data(), ndev, out);
     }
-    rt_scene *s = new rt_scene();
-    int rc = create_impl(desc, device, s);
-    if (rc != RT_OK) {
-        delete s;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) // before any host work: without a GPU nothing below can succeed
+        return rt::fail(RT_ERR_NO_DEVICE, "rt_create: no HIP device available (this library has no CPU fallback)");
+    std::shared_ptr<const rt::PreparedScene> prep;
+    if (int rc = rt::prepare(desc, &prep); rc != RT_OK)
         return rc;
-    }
-    *out = s;
-    return RT_OK;
+    return rt::create_replica(desc, prep, device, out);
 }
 
 extern "C" int rt_scene_device_count(const rt_scene *scene) { return !scene ? 0 : (scene->group ? rt::group_size(scene->group) : 1); }
@@ -1144,7 +1207,7 @@ static int reconstruct_host_bvh(rt_scene *s) {
         HIP_TRY(hipMemcpy(nodes.data(), s->dev.scene.nodes, sizeof(DevNode) * (size_t)n_inner, hipMemcpyDeviceToHost));
     if (n_tris)
         HIP_TRY(hipMemcpy(tris.data(), s->dev.scene.tris, sizeof(DevTri) * (size_t)n_tris, hipMemcpyDeviceToHost));
-    rt::HostBvh &hb = s->host_bvh[0];
+    rt::HostBvh &hb = s->rebuilt_bvh;
     hb.nodes.clear();
     hb.order.resize(n_tris);
     for (uint32_t k = 0; k < n_tris; ++k)
@@ -1231,10 +1294,10 @@ extern "C" int rt_bvh_info(rt_scene *s, int which, uint32_t *n_nodes, uint32_t *
         return rt_bvh_info(rt::group_primary(s->group), which, n_nodes, n_objects, root, nodes_out, order_out);
     if (which == 0 && s->device_built && s->wide_built)
         return rt::fail(RT_ERR_UNSUPPORTED, "rt_bvh_info: the binary tree of a device-built wide scene is not kept");
-    if (which == 0 && s->device_built && s->host_bvh[0].nodes.empty() && s->dev.scene.n_tris)
+    if (which == 0 && s->device_built && s->rebuilt_bvh.nodes.empty() && s->dev.scene.n_tris)
         if (int rc = reconstruct_host_bvh(s); rc != RT_OK)
             return rc;
-    const rt::HostBvh &b = s->host_bvh[which];
+    const rt::HostBvh &b = (which == 0 && s->device_built) ? s->rebuilt_bvh : s->prep->host_bvh[which];
     if (n_nodes)
         *n_nodes = (uint32_t)b.nodes.size();
     if (n_objects)

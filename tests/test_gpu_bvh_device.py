@@ -3,8 +3,8 @@
     flattening (in numpy) of the reference-style node list the CPU tests pin to the reference's BVH dumps;
   * device LBVH build (RT_BUILD_DEVICE_LBVH, csrc/rt_bvh_device.hip): a different topology, validated by
     invariants (every triangle in exactly one leaf, every stored child box is the exact bounding box of its subtree, bounded
-    depth and leaf size) and by closest-hit equality against the reference-topology BVH of the same scene: identical t,
-    bit for bit, on 10^5 rays (equal-t ties may name another triangle)."""
+    depth and leaf size) and by closest-hit equality against the CPU ORACLE (never another GPU scene): identical t, bit for
+    bit, on 10^5 rays; an index may differ only on an exact tie, and the tie share is asserted against a number."""
 import numpy as np
 import pytest
 
@@ -106,19 +106,23 @@ def _check_invariants(dump, positions, max_leaf=4):
     return max_depth
 
 
-def _compare_hits(a, b, rays):
-    ap, ab = a.cast_rays(rays)
-    bp, bb = b.cast_rays(rays)
-    assert np.array_equal(ap == 0xFFFFFFFF, bp == 0xFFFFFFFF)
-    assert np.array_equal(ab[:, 2].view(np.uint32), bb[:, 2].view(np.uint32)), "closest-hit distance differs between the two BVHs"
-    same = ap == bp
-    assert same.mean() > 0.995  # the rest are exact ties in t between two triangles (first one in leaf order wins)
-    assert np.array_equal(ab[same].view(np.uint32), bb[same].view(np.uint32))
-    return float(1 - same.mean())
+def _compare_hits_with_oracle(orc, dev, rays, max_tie_share):
+    """Closest hits of a device-built tree against the oracle's: t bit-equal on every ray, same hit / miss; where the index agrees
+    the barycentrics are bit-equal too; where it differs the two triangles tie exactly in t (asserted by the first check)."""
+    op, ob = orc.cast_rays(rays)
+    gp, gb = dev.cast_rays(rays)
+    assert np.array_equal(op == 0xFFFFFFFF, gp == 0xFFFFFFFF)
+    bad = ob[:, 2].view(np.uint32) != gb[:, 2].view(np.uint32)
+    assert not bad.any(), f"closest-hit distance differs from the oracle on {int(bad.sum())} of {len(rays)} rays"
+    same = op == gp
+    assert np.array_equal(gb[same].view(np.uint32), ob[same].view(np.uint32))
+    share = float(1 - same.mean())
+    assert share <= max_tie_share, f"{int((~same).sum())} index mismatches (exact ties) of {len(rays)} rays: more than {max_tie_share:.1e}"
+    return share
 
 
 @pytest.mark.parametrize("case", ["room_5000", "boxes", "tiny_1", "tiny_2", "tiny_5", "tiny_9", "room_1M"])
-def test_device_lbvh_invariants_and_closest_hits(gpu, sg, case):
+def test_device_lbvh_invariants_and_closest_hits(gpu, oracle, sg, case):
     if case.startswith("room"):
         n = 5000 if case == "room_5000" else 1_000_000
         sc = sg.room_scene(n, seed=3, n_lights=6, n_materials=8, tex_size=8, n_tex_sets=2, offset=0.15 if n == 5000 else 0.05)
@@ -132,7 +136,7 @@ def test_device_lbvh_invariants_and_closest_hits(gpu, sg, case):
         sc = sg.Scene(positions=pos, normals=None, texcoords=np.zeros((k, 3, 2), np.float32), tangents=tan, material_ids=np.zeros(k, np.uint32),
                       materials=[sg.Material(color=(0.7, 0.7, 0.7, 1.0), roughness=1.0, metallic=0.0)], textures=[],
                       camera=sg.look_camera((0.0, 0.0, 6.0), yaw_deg=0.0, yfov=0.9))
-    ref = gpu.DeviceScene(sc)
+    orc = oracle.OracleScene(sc)
     dev = gpu.DeviceScene(sc, device_bvh=True)
     try:
         dump = dev.bvh_device_dump(0)
@@ -142,18 +146,21 @@ def test_device_lbvh_invariants_and_closest_hits(gpu, sg, case):
         assert (leaves[:, 9] - leaves[:, 8]).sum() == sc.n_triangles and sorted(info["order"].tolist()) == list(range(sc.n_triangles))
         n_rays = 100_000 if sc.n_triangles >= 5000 else 20_000
         rays = random_rays(sc, n_rays, seed=12)
-        ties = _compare_hits(ref, dev, rays)
-        # the render loop runs unchanged on the device-built tree: finite image, both schedules agree, close to the reference tree's
+        # random triangle soups do not tie; the boxes scene does along the shared diagonal of a face's two triangles
+        ties = _compare_hits_with_oracle(orc, dev, rays, max_tie_share=2e-3 if case == "boxes" else 5e-5)
+        # the render loop runs unchanged on the device-built tree: both schedules agree, and the image is the ORACLE's wherever
+        # no path met an exact tie
         W, H, SPP = (96, 64, 4) if sc.n_triangles >= 5000 else (48, 32, 4)
-        a, _ = ref.run_raytracer(W, H, SPP, seed=5)
+        a, _ = orc.run_raytracer(W, H, SPP, seed=5)
         b, _ = dev.run_raytracer(W, H, SPP, seed=5)
         m, _ = dev.run_raytracer(W, H, SPP, seed=5, megakernel=True)
         assert np.isfinite(b).all() and np.array_equal(b.view(np.uint32), m.view(np.uint32))
-        differing = float((a != b).any(axis=2).mean())
-        assert differing < 0.02, differing  # only paths through an exact tie can differ
-        t_ref, t_dev = ref.build_times(), dev.build_times()
-        print(f"\\n[{case}] triangles {sc.n_triangles}: host reference-topology build {t_ref['build_ms']:.1f} ms; device LBVH build {t_dev['build_ms']:.2f} ms "
-              f"(+ upload {t_dev['upload_ms']:.1f} ms), depth {depth}, tie share {ties:.2e}, differing pixels {differing:.2e}")
+        rel = np.abs(a - b) / np.maximum(np.abs(a), 1e-6)
+        differing = float((rel > 1e-5).any(axis=2).mean())
+        assert differing <= (0.02 if case == "boxes" else 0.002), differing  # only paths through an exact tie can differ
+        t_dev = dev.build_times()
+        print(f"\\n[{case}] triangles {sc.n_triangles}: device LBVH build {t_dev['build_ms']:.2f} ms (+ upload {t_dev['upload_ms']:.1f} ms), depth {depth}, "
+              f"tie share vs oracle {ties:.2e}, pixels beyond 1e-5 of the oracle {differing:.2e}")
     finally:
-        ref.close()
+        orc.close()
         dev.close()
