@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_summarize.py <workload> <tag> <pmc_spp> — turn the rocprofv3 outputs of tools/profile_round.sh (under
+"""tools/pmc_summarize.py <workload> <tag> <pmc_spp> [mode] — turn the rocprofv3 outputs of tools/profile_round.sh (under
 gpurun_out/) into the small stamped summaries bench.py reads from profiles/:
     <tag>_hbm_traffic_<wl>.json     FETCH_SIZE / WRITE_SIZE per wf_extend launch, corrected as MI355X_MICROARCH.md says
     <tag>_pmc_<kernel>_<wl>.json    SQ / TCP / TCC counters of wf_extend and wf_shade + derived ratios + a one-line limiter
@@ -17,11 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_source_hash, WORKLOADS)
 
-wl, tag, pmc_spp = sys.argv[1], sys.argv[2], int(sys.argv[3])
+wl_name, tag, pmc_spp = sys.argv[1], sys.argv[2], int(sys.argv[3])
+mode = sys.argv[4] if len(sys.argv) > 4 else "parity"
+wl = wl_name + bench.MODES[mode]["suffix"]  # = bench.py's workload_id: names the output files
 O = os.path.join(ROOT, "gpurun_out")
-W = bench.WORKLOADS[wl]
+W = bench.WORKLOADS[wl_name]
+# the closest-hit kernels of this mode (every one of their launches is what bench.py times as "the dominant kernel")
+EXTEND = ("wf_extend_wide<false",) if mode == "wide" else ("wf_extend<false", "wf_extend_packet<false")
 sha = bench.kernel_source_hash()
-workload = f"{W['label']} {W['width']}x{W['height']} n={W['triangles']}"
+workload = f"{W['label']} {W['width']}x{W['height']} n={W['triangles']} mode={mode}"
 
 
 def collect(dirglob, kernel):
@@ -41,12 +45,12 @@ def collect(dirglob, kernel):
 # ---- HBM traffic of wf_extend (full-SPP passes of the default command: same launch structure as the bench)
 # both closest-hit kernels: wf_extend<false> (bounces >= 1, and bounce 0 when packets do not pay) and wf_extend_packet<false> (primary
 # rays), i.e. the launches bench.py times as "the dominant kernel" (one HIP-event pair per closest-hit launch)
-agg, dur, n = collect(f"{tag}_pmc_*_SIZE_{wl}", ("wf_extend<false>", "wf_extend_packet<false>"))
+agg, dur, n = collect(f"{tag}_pmc_*_SIZE_{wl}", EXTEND)
 if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
     fetch = agg["FETCH_SIZE"] / n["FETCH_SIZE"]
     write = agg["WRITE_SIZE"] / n["WRITE_SIZE"]
     out = {
-        "workload": f"{workload} spp={W['spp_per_gpu']}", "kernel": "wf_extend<false> + wf_extend_packet<false> (every closest-hit launch)", "kernel_src_sha16": sha, "launches": n["FETCH_SIZE"],
+        "workload": f"{workload} spp={W['spp_per_gpu']}", "kernel": " + ".join(EXTEND) + "...> (every closest-hit launch)", "kernel_src_sha16": sha, "launches": n["FETCH_SIZE"],
         # MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 64 B per L2 read request although a request moves a 128-B line ->
         # doubled, as the guide prescribes. The guide also says "other access widths are uncalibrated: calibrate on a known
         # byte count in your own access pattern": tools/ubench/gather64.hip (profiles/r02_gather64_calibration.txt) shows
@@ -59,7 +63,7 @@ if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
         "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
         "avg_launch_ms_under_pmc": dur["FETCH_SIZE"] / n["FETCH_SIZE"],
         "correction": "gfx950: FETCH_SIZE reports 64 B per 128-B read request -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; x1024 (KB)",
-        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over python3 bench.py (one warm-up render first: the packet policy has settled) {'--workload ' + wl if wl != 'sponza' else ''} --no-cpu-baseline --steps 1 --warmup 0, averaged over the wf_extend<false> and wf_extend_packet<false> dispatches",
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over python3 bench.py (one warm-up render first: the packet policy has settled) --workload {wl_name} --mode {mode} --no-extras --no-cpu-baseline --steps 1 --warmup 1, averaged over the closest-hit dispatches",
     }
     json.dump(out, open(os.path.join(O, f"{tag}_hbm_traffic_{wl}.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
@@ -67,14 +71,14 @@ else:
     print("no FETCH_SIZE/WRITE_SIZE data", dict(agg))
 
 # ---- SQ / TCP / TCC counters
-for kern, short in (("wf_extend<false>", "wf_extend"), ("wf_extend_packet<false>", "wf_extend_packet"), ("wf_shade<false", "wf_shade")):
+for kern, short in ((("wf_extend_wide<false",) if mode == "wide" else ("wf_extend<false",), "wf_extend"), (("wf_extend_packet<false",), "wf_extend_packet"), (("wf_shade<false",), "wf_shade")):
     agg, dur, n = collect(f"{tag}_pmc_sq*_{wl}", kern)
     if not agg:
         print("no SQ data for", kern)
         continue
     g = lambda k: agg.get(k, 0.0)  # noqa: E731
     simds = 256 * 4
-    d = {"workload": workload, "spp": pmc_spp, "kernel": kern, "kernel_src_sha16": sha, "dispatches": max(n.values()),
+    d = {"workload": workload, "spp": pmc_spp, "kernel": kern[0] + "...>", "kernel_src_sha16": sha, "dispatches": max(n.values()),
          "kernel_ms_sum_under_pmc": max(dur.values()), "raw": {k: agg[k] for k in sorted(agg)}}
     # SQ_BUSY_CYCLES is summed over the SQs (one per shader engine: 32); SQ_WAVE_CYCLES etc. are in quad-cycles (x4)
     if g("SQ_BUSY_CYCLES") and g("SQ_INSTS_VALU"):
@@ -114,7 +118,7 @@ for kern, short in (("wf_extend<false>", "wf_extend"), ("wf_extend_packet<false>
                         f"L2 hit {d.get('l2_hit')}; not HBM bandwidth (see hbm_frac)")
         if d.get("l1_frac") is not None and d["l1_frac"] >= 0.6:
             d["limiter"] = (f"vector-L1 access rate: {d['l1_accesses_per_clk_per_cu']} tag accesses per clock per CU = {d['l1_frac']:.2f} of the measured 0.98 roof "
-                            f"(4 accesses per 64-B node per lane), {d.get('l1_pending_stall_frac', 0) * 100:.0f} % of L1 cycles stalled on pending misses; "
+                            f"({'5 accesses per 80-B wide node' if mode == 'wide' else '4 accesses per 64-B node'} per lane), {d.get('l1_pending_stall_frac', 0) * 100:.0f} % of L1 cycles stalled on pending misses; "
                             f"VALU issue {vb * 100:.0f} % at {la} of 64 lanes, waves waiting {wa * 100 if wa else 0:.0f} %, L1 hit {d.get('l1_hit')}, L2 hit {d.get('l2_hit')}; "
                             "not HBM bandwidth (see hbm_frac)")
     path = os.path.join(O, f"{tag}_pmc_{short}_{wl}.json")
