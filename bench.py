@@ -457,7 +457,7 @@ def main() -> None:
             rf = r.roofline()
             out[mode] = {"traversal": MODES[mode]["text"], "workload_id": r.workload_id, "value": round(v, 3), "unit": "Msamples/s", "steps": steps_, "warmup": warm_,
                          "ms_per_step": round(r.elapsed / steps_ * 1e3, 3), "vs_parity": round(v / parity_value, 3) if parity_value else None,
-                         "rt_create_s": round(r.t_create, 2), "roofline": rf}
+                         "rt_create_s": round(r.t_create, 2), "build_ms": {k: round(v, 2) for k, v in r.build_times.items()}, "roofline": rf}
             r.close()
         out["parity_of_these_modes"] = ("tests/test_gpu_production.py, against the CPU oracle: closest-hit t bit-equal on every ray (5 fixtures, S-sponza 60 000 rays, S-10M 100 000 rays), "
                                         "index differences only on exact ties, the S-sponza 1000x1000x1 SPP framebuffer bit-identical to the oracle's; the wide tree may find a hit "

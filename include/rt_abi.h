@@ -271,6 +271,8 @@ int rt_bvh_device_dump(rt_scene *scene, int which, uint32_t *n_inner, uint32_t *
 int rt_bvh_wide_dump(rt_scene *scene, uint32_t *n_nodes, uint32_t *n_tris, uint32_t *depth, uint32_t *nodes80, uint32_t *tris48);
 /* Wall time of the last rt_create's scene-BVH build in ms: {host build + flatten, 0} or {device build, upload of the raw arrays}. */
 int rt_build_times(const rt_scene *scene, double *build_ms, double *upload_ms);
+/* ... and of the wide collapse on top of it (RT_BUILD_WIDE; 0 otherwise): on the host (wide_build.cpp) after a host build, on the device after a device build. */
+int rt_build_times_ex(const rt_scene *scene, double *build_ms, double *upload_ms, double *wide_ms);
 
 /* Film (image.h:49-82): ACES -> gamma 1/2.2 -> x255 -> clamp -> round -> u8. Host function; n pixels. */
 void rt_tonemap_rgb8(const float *rgb, size_t n_pixels, uint8_t *out_rgb8);

@@ -284,9 +284,9 @@ class DeviceScene:
         return {"depth": dp.value, "nodes": nodes, "tris": tris}
 
     def build_times(self):
-        b, u = C.c_double(), C.c_double()
-        _check(lib().rt_build_times(self._h, C.byref(b), C.byref(u)))
-        return {"build_ms": b.value, "upload_ms": u.value}
+        b, u, w = C.c_double(), C.c_double(), C.c_double()
+        _check(lib().rt_build_times_ex(self._h, C.byref(b), C.byref(u), C.byref(w)))
+        return {"build_ms": b.value, "upload_ms": u.value, "wide_ms": w.value}
 
     def bvh_info(self, which: int):
         nn, no, root = C.c_uint32(), C.c_uint32(), C.c_uint32()

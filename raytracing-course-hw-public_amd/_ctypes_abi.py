@@ -161,6 +161,7 @@ ABI_PROTOTYPES = {
     "rt_scene_device_count": (C.c_int, [C.c_void_p]),
     "rt_bvh_device_dump": (C.c_int, [C.c_void_p, C.c_int, c_u32_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
     "rt_build_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rt_build_times_ex": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 HOST_PROTOTYPES = {
     "rt_gltf_load": (C.c_int, [C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),

@@ -8,7 +8,10 @@
 namespace rt {
 
 struct DeviceBvh {
-    DevNode *nodes = nullptr; // device memory, owned by the caller after a successful build
+    DevNode *nodes = nullptr; // device memory, owned by the caller after a successful build (null when `wide` was built)
+    WideNode *wide = nullptr; // the 8-wide tree, collapsed on the device (tris / attrs are then in ITS order)
+    uint32_t n_wide = 0, wide_depth = 0;
+    double wide_ms = 0;
     DevTri *tris = nullptr;
     DevAttr *attrs = nullptr;
     uint32_t n_inner = 0, n_tris = 0, root = RT_NONE;
@@ -18,6 +21,9 @@ struct DeviceBvh {
 };
 
 // Linear BVH over all triangles of `d`, built on the current device on `stream` (blocking). On failure *err names the call.
-hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBvh *out, const char **err);
+// `wide`: also collapse it into the 8-wide quantised tree ON THE DEVICE (the dynamic program of wide_build.cpp inside the refit,
+// then a top-down emission, level by level) and keep only that; ignored for scenes of <= 8 triangles (out->wide stays null).
+hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBvh *out, const char **err, bool wide = false, float cost_node = 1.0f,
+                            float cost_tri = 0.3f);
 
 } // namespace rt

@@ -131,6 +131,11 @@ struct BuildArrays {
     uint32_t *leaf_parent, *node_parent;
     uint32_t *arrived; // [n_leaves - 1]
     uint32_t *fast_bad; // set to 1 if a coordinate violates the div_exact_fast range (rt_device_lib.h)
+    // wide collapse (RT_BUILD_WIDE on top of the device tree): the dynamic program of wide_build.cpp, filled by k_refit
+    float *dp_cost;                // [n_leaves - 1][7]: C(n, i), i = 1..7; null = no collapse wanted
+    unsigned long long *dp_dec;    // [n_leaves - 1]: ksplit(j = 2..8) 3 bits each from bit 0, eff(i = 1..7) 3 bits each from bit 21, as_leaf bit 42
+    uint32_t *dp_ntris;            // [n_leaves - 1]: triangles below
+    float cost_node, cost_tri;
 };
 
 __device__ __forceinline__ bool coord_fast_ok(float c) {
@@ -250,6 +255,11 @@ __global__ __launch_bounds__(256) void k_radix_tree(const BuildArrays A) {
     }
 }
 
+__device__ __forceinline__ float box_area6(const float *b) { // surface area of {lo.xyz, hi.xyz}; 0 for an inverted / NaN box
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return (dx >= 0.0f && dy >= 0.0f && dz >= 0.0f) ? 2.0f * (dx * dy + dy * dz + dz * dx) : 0.0f;
+}
+
 // ---- 5. refit: the second arrival at a node owns it. Hand-off between workgroups: the first arrival has stored its
 // subtree's box, fenced (agent-scope release) and bumped the counter; the second one sees counter == 1, fences
 // (agent-scope acquire) and reads that box (MI355X_MICROARCH.md, inter-workgroup visibility).
@@ -293,11 +303,329 @@ __global__ __launch_bounds__(256) void k_refit(const BuildArrays A) {
                 box[c] = fminf(l6[c], r6[c]);
                 box[3 + c] = fmaxf(l6[3 + c], r6[3 + c]);
             }
+            if (A.dp_cost) { // the wide collapse's dynamic program for this node (wide_build.cpp step 2), children first by construction
+                const float INF = __builtin_inff();
+                float cl[7], cr[7];
+                uint32_t nl = 1u, nr = 1u;
+                if (lref & RT_LEAF_FLAG) {
+                    const float a = box_area6(l6) * A.cost_tri;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i)
+                        cl[i] = a;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 7; ++i)
+                        cl[i] = __hip_atomic_load(A.dp_cost + 7ull * lref + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nl = __hip_atomic_load(A.dp_ntris + lref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (rref & RT_LEAF_FLAG) {
+                    const float a = box_area6(r6) * A.cost_tri;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i)
+                        cr[i] = a;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 7; ++i)
+                        cr[i] = __hip_atomic_load(A.dp_cost + 7ull * rref + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nr = __hip_atomic_load(A.dp_ntris + rref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const float area = box_area6(box);
+                const uint32_t nt = nl + nr;
+                unsigned long long dec = 0ull;
+                float dist[9];
+#pragma unroll
+                for (int j = 2; j <= 8; ++j) {
+                    float best = INF;
+                    int bk = 1;
+#pragma unroll
+                    for (int k = 1; k < j; ++k) {
+                        if (k > 7 || j - k > 7)
+                            continue;
+                        const float c = cl[k - 1] + cr[j - k - 1];
+                        if (c < best) {
+                            best = c;
+                            bk = k;
+                        }
+                    }
+                    dist[j] = best;
+                    dec |= (unsigned long long)bk << (3 * (j - 2));
+                }
+                const float c_leaf = nt <= RT_WIDE_MAX_LEAF_TRIS ? area * (float)nt * A.cost_tri : INF;
+                const float c_internal = dist[8] + area * A.cost_node;
+                if (c_leaf <= c_internal)
+                    dec |= 1ull << 42;
+                float c[7];
+                int eff = 1;
+                c[0] = fminf(c_leaf, c_internal);
+                dec |= 1ull << 21;
+#pragma unroll
+                for (int i = 2; i <= 7; ++i) {
+                    if (dist[i] < c[i - 2]) {
+                        c[i - 1] = dist[i];
+                        eff = i;
+                    } else {
+                        c[i - 1] = c[i - 2];
+                    }
+                    dec |= (unsigned long long)eff << (21 + 3 * (i - 1));
+                }
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+                    A.dp_cost[7ull * node + i] = c[i];
+                A.dp_ntris[node] = nt;
+                A.dp_dec[node] = dec;
+            }
             child_is_leaf = 0u;
             child = node;
             node = A.node_parent[node];
         }
     }
+}
+
+// ---- 6. wide collapse, top down (RT_BUILD_WIDE on the device tree): one thread per wide node of the current level.
+// The node's children are the roots its binary subtree was cut into by the dynamic program (same decisions, same left-to-right
+// order as wide_build.cpp's `collect`); slots by octant (greedy on centroid . corner direction), boxes quantised floor / ceil on
+// the node's power-of-two grid; inner children get consecutive records (one atomic per node), leaf slots consecutive triangle
+// records (one atomic per node) copied from the Morton-ordered DevTri / DevAttr arrays of step 3.
+struct WideEmit {
+    const DevNode *nodes;               // the binary tree (inner nodes)
+    const float *leaf_box;              // [n_leaves][6]
+    const unsigned long long *dp_dec;
+    const DevTri *tris_in;              // Morton order, one triangle per binary leaf
+    const DevAttr *attrs_in;
+    WideNode *wide;
+    DevTri *tris_out;
+    DevAttr *attrs_out;
+    const uint2 *queue_in;              // {binary inner node, wide record index}
+    uint2 *queue_out;
+    uint32_t n_in;
+    uint32_t *counters;                 // [0] wide records allocated, [1] triangle records allocated, [2] entries of queue_out
+};
+__device__ __forceinline__ uint32_t dec_ksplit(unsigned long long d, int j) { return (uint32_t)(d >> (3 * (j - 2))) & 7u; }
+__device__ __forceinline__ uint32_t dec_eff(unsigned long long d, int i) { return (uint32_t)(d >> (21 + 3 * (i - 1))) & 7u; }
+__device__ __forceinline__ bool dec_as_leaf(unsigned long long d) { return (d >> 42) & 1ull; }
+
+__global__ __launch_bounds__(64) void k_wide_emit(const WideEmit E) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= E.n_in)
+        return;
+    const uint32_t bnode = E.queue_in[q].x, widx = E.queue_in[q].y;
+    // ---- the roots this node's subtree is cut into
+    uint32_t kid[8];   // binary ref: inner index, or RT_LEAF_FLAG | ... for a single-triangle leaf
+    bool kid_leaf[8];  // becomes a leaf slot (a binary leaf, or an inner node of <= 3 triangles the program chose to keep whole)
+    float kbox[8][6];
+    int nk = 0;
+    {
+        uint32_t st_ref[16];
+        uint32_t st_i[16];
+        float st_box[16][6];
+        int sp = 0;
+        const DevNode nd = E.nodes[bnode];
+        const uint32_t k = dec_ksplit(E.dp_dec[bnode], 8);
+        st_ref[sp] = nd.right, st_i[sp] = 8u - k;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            st_box[sp][c] = nd.rmin[c], st_box[sp][3 + c] = nd.rmax[c];
+        ++sp;
+        st_ref[sp] = nd.left, st_i[sp] = k;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            st_box[sp][c] = nd.lmin[c], st_box[sp][3 + c] = nd.lmax[c];
+        ++sp;
+        while (sp > 0) {
+            --sp;
+            const uint32_t m = st_ref[sp], i = st_i[sp];
+            float b[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                b[c] = st_box[sp][c];
+            bool root_here = (m & RT_LEAF_FLAG) != 0u;
+            unsigned long long d = 0ull;
+            uint32_t j = 1u;
+            if (!root_here) {
+                d = E.dp_dec[m];
+                j = dec_eff(d, (int)i);
+                root_here = j == 1u;
+            }
+            if (root_here) {
+                kid[nk] = m;
+                kid_leaf[nk] = (m & RT_LEAF_FLAG) != 0u || dec_as_leaf(d);
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    kbox[nk][c] = b[c];
+                ++nk;
+                continue;
+            }
+            const DevNode mn = E.nodes[m];
+            const uint32_t kk = dec_ksplit(d, (int)j);
+            st_ref[sp] = mn.right, st_i[sp] = j - kk;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                st_box[sp][c] = mn.rmin[c], st_box[sp][3 + c] = mn.rmax[c];
+            ++sp;
+            st_ref[sp] = mn.left, st_i[sp] = kk;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                st_box[sp][c] = mn.lmin[c], st_box[sp][3 + c] = mn.lmax[c];
+            ++sp;
+        }
+    }
+    // ---- node box, grid
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = 0; i < nk; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = fminf(lo[c], kbox[i][c]);
+            hi[c] = fmaxf(hi[c], kbox[i][3 + c]);
+        }
+    WideNode rec;
+    int ebias[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        rec.p[c] = lo[c];
+        const double ext = (double)hi[c] - (double)lo[c];
+        int e = -126;
+        if (ext > 0.0) {
+            e = (int)ceil(log2(ext / 255.0));
+            e = e < -126 ? -126 : e;
+            while (ldexp(255.0, e) < ext) // rounding of log2: the grid must span the box
+                ++e;
+            e = e > 126 ? 126 : e;
+        }
+        ebias[c] = e + 127;
+        rec.e[c] = (uint8_t)ebias[c];
+    }
+    // ---- slots: greedy on dot(child centre - node centre, corner direction of the slot)
+    int child_in[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        child_in[s] = -1;
+    uint32_t assigned = 0u;
+    for (int round = 0; round < nk; ++round) {
+        float best = -__builtin_inff();
+        int bi = -1, bs = -1;
+        for (int i = 0; i < nk; ++i) {
+            if (assigned & (1u << i))
+                continue;
+            float dc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                dc[c] = 0.5f * (kbox[i][c] + kbox[i][3 + c]) - 0.5f * (lo[c] + hi[c]);
+            for (int s = 0; s < 8; ++s) {
+                if (child_in[s] >= 0)
+                    continue;
+                const float sc = dc[0] * ((s & 1) ? 1.0f : -1.0f) + dc[1] * ((s & 2) ? 1.0f : -1.0f) + dc[2] * ((s & 4) ? 1.0f : -1.0f);
+                if (sc > best) {
+                    best = sc;
+                    bi = i;
+                    bs = s;
+                }
+            }
+        }
+        if (bi < 0) { // NaN boxes: any free pairing
+            for (int i = 0; i < nk && bi < 0; ++i)
+                if (!(assigned & (1u << i)))
+                    bi = i;
+            for (int s = 0; s < 8 && bs < 0; ++s)
+                if (child_in[s] < 0)
+                    bs = s;
+        }
+        child_in[bs] = bi;
+        assigned |= 1u << bi;
+    }
+    // ---- counts, allocation
+    uint32_t n_inner = 0, n_tri = 0;
+    uint32_t cnt[8];
+    for (int s = 0; s < 8; ++s) {
+        cnt[s] = 0;
+        const int i = child_in[s];
+        if (i < 0)
+            continue;
+        if (!kid_leaf[i])
+            ++n_inner;
+        else {
+            // triangles below: 1 for a binary leaf; an inner node kept whole has 2 or 3 single-triangle leaves below it
+            uint32_t n = 1;
+            if (!(kid[i] & RT_LEAF_FLAG)) {
+                const DevNode a = E.nodes[kid[i]];
+                n = 0;
+                const uint32_t sub[2] = {a.left, a.right};
+                for (int t = 0; t < 2; ++t) {
+                    if (sub[t] & RT_LEAF_FLAG)
+                        n += 1;
+                    else
+                        n += 2; // <= 3 triangles in all: an inner grandchild holds exactly two leaves
+                }
+            }
+            cnt[s] = n;
+            n_tri += n;
+        }
+    }
+    const uint32_t first_child = n_inner ? atomicAdd(E.counters + 0, n_inner) : 0u;
+    const uint32_t tri_base = n_tri ? atomicAdd(E.counters + 1, n_tri) : 0u;
+    const uint32_t qbase = n_inner ? atomicAdd(E.counters + 2, n_inner) : 0u;
+    rec.imask = 0;
+    rec.child_base = first_child;
+    rec.tri_base = tri_base;
+    rec.tri_mask = 0;
+    rec.pad = 0;
+    uint32_t r_inner = 0, r_tri = 0;
+    for (int s = 0; s < 8; ++s) {
+        const int i = child_in[s];
+        if (i < 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rec.qlo[c][s] = 255; // empty slot: inverted box
+                rec.qhi[c][s] = 0;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double cell = ldexp(1.0, ebias[c] - 127);
+            double ql = floor(((double)kbox[i][c] - (double)lo[c]) / cell), qh = ceil(((double)kbox[i][3 + c] - (double)lo[c]) / cell);
+            ql = fmin(fmax(ql, 0.0), 255.0);
+            qh = fmin(fmax(qh, 0.0), 255.0);
+            while (ql > 0.0 && (double)lo[c] + ql * cell > (double)kbox[i][c])
+                ql -= 1.0;
+            while (qh < 255.0 && (double)lo[c] + qh * cell < (double)kbox[i][3 + c])
+                qh += 1.0;
+            rec.qlo[c][s] = (uint8_t)ql;
+            rec.qhi[c][s] = (uint8_t)qh;
+        }
+        if (!kid_leaf[i]) {
+            rec.imask |= (uint8_t)(1u << s);
+            E.queue_out[qbase + r_inner] = make_uint2(kid[i], first_child + r_inner);
+            ++r_inner;
+        } else {
+            // the slot's triangles, left to right
+            uint32_t leaves[3];
+            uint32_t nl = 0;
+            if (kid[i] & RT_LEAF_FLAG) {
+                leaves[nl++] = kid[i] & RT_LEAF_BEGIN_MASK;
+            } else {
+                const DevNode a = E.nodes[kid[i]];
+                const uint32_t sub[2] = {a.left, a.right};
+                for (int t = 0; t < 2; ++t) {
+                    if (sub[t] & RT_LEAF_FLAG) {
+                        leaves[nl++] = sub[t] & RT_LEAF_BEGIN_MASK;
+                    } else {
+                        const DevNode g = E.nodes[sub[t]];
+                        leaves[nl++] = g.left & RT_LEAF_BEGIN_MASK;
+                        leaves[nl++] = g.right & RT_LEAF_BEGIN_MASK;
+                    }
+                }
+            }
+            for (uint32_t t = 0; t < nl && t < RT_WIDE_MAX_LEAF_TRIS; ++t) {
+                rec.tri_mask |= 1u << (3 * s + (int)t);
+                DevTri tr = E.tris_in[leaves[t]];
+                tr.flags = 0;
+                E.tris_out[tri_base + r_tri] = tr;
+                E.attrs_out[tri_base + r_tri] = E.attrs_in[leaves[t]];
+                ++r_tri;
+            }
+        }
+    }
+    E.wide[widx] = rec;
 }
 
 struct Tmp { // device allocations of the build, freed on every return path
@@ -330,7 +658,7 @@ namespace rt {
         }                          \
     } while (0)
 
-hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBvh *out, const char **err) {
+hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBvh *out, const char **err, bool wide, float cost_node, float cost_tri) {
     const uint32_t n = d->n_triangles;
     *out = DeviceBvh{};
     out->root = RT_NONE;
@@ -344,6 +672,10 @@ hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBv
     uint32_t leaf_tris = LEAF_TRIS_DEFAULT;
     if (const char *e = std::getenv("RT_LBVH_LEAF"))
         leaf_tris = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
+    // the wide collapse regroups single-triangle leaves itself; scenes of a handful of triangles take the host collapse (rt_scene.cpp)
+    wide = wide && n > 8u;
+    if (wide)
+        leaf_tris = 1;
     const uint32_t n_leaves = (n + leaf_tris - 1) / leaf_tris;
     BUILD_TRY(tmp.alloc(&pos, 9ull * n));
     BUILD_TRY(tmp.alloc(&nrm, 9ull * n));
@@ -406,6 +738,12 @@ hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBv
     BUILD_TRY(tmp.alloc(&node_parent, (size_t)n_leaves));
     BUILD_TRY(tmp.alloc(&arrived, (size_t)n_leaves));
     A.leaf_parent = leaf_parent, A.node_parent = node_parent, A.arrived = arrived, A.fast_bad = fast_bad;
+    A.cost_node = cost_node, A.cost_tri = cost_tri;
+    if (wide) {
+        BUILD_TRY(tmp.alloc(&A.dp_cost, 7ull * n_leaves));
+        BUILD_TRY(tmp.alloc(&A.dp_dec, (size_t)n_leaves));
+        BUILD_TRY(tmp.alloc(&A.dp_ntris, (size_t)n_leaves));
+    }
     BUILD_TRY(hipMemsetAsync(arrived, 0, 4ull * n_leaves, stream));
     BUILD_TRY(hipMemsetAsync(leaf_parent, 0xFF, 4ull * n_leaves, stream)); // RT_NONE: a single leaf has no parent
     const int lblocks = (int)std::min<uint64_t>(((uint64_t)n_leaves + 255) / 256, 256u * 16u);
@@ -419,7 +757,63 @@ hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBv
     BUILD_TRY(hipStreamSynchronize(stream));
     const auto t2 = std::chrono::steady_clock::now();
 
+    // ---- wide collapse on the device: level by level from the root; the host only reads each level's size
+    WideNode *wide_nodes = nullptr;
+    DevTri *wide_tris = nullptr;
+    DevAttr *wide_attrs = nullptr;
+    uint32_t n_wide = 0, wide_depth = 0;
+    if (wide) {
+        uint2 *queue[2];
+        uint32_t *counters;
+        BUILD_TRY(out_alloc((void **)&wide_nodes, sizeof(WideNode) * (size_t)n_leaves)); // <= one wide node per binary inner node
+        BUILD_TRY(out_alloc((void **)&wide_tris, sizeof(DevTri) * (size_t)n));
+        BUILD_TRY(out_alloc((void **)&wide_attrs, sizeof(DevAttr) * (size_t)n));
+        BUILD_TRY(tmp.alloc(&queue[0], (size_t)n_leaves));
+        BUILD_TRY(tmp.alloc(&queue[1], (size_t)n_leaves));
+        BUILD_TRY(tmp.alloc(&counters, (size_t)4));
+        const uint32_t init_counters[4] = {1u, 0u, 0u, 0u}; // record 0 = the root
+        const uint2 root_entry = make_uint2(0u, 0u);         // binary inner node 0 (Karras: the root) -> wide record 0
+        BUILD_TRY(hipMemcpyAsync(counters, init_counters, sizeof(init_counters), hipMemcpyHostToDevice, stream));
+        BUILD_TRY(hipMemcpyAsync(queue[0], &root_entry, sizeof(root_entry), hipMemcpyHostToDevice, stream));
+        BUILD_TRY(hipStreamSynchronize(stream));
+        WideEmit E{};
+        E.nodes = A.nodes, E.leaf_box = A.leaf_box, E.dp_dec = A.dp_dec, E.tris_in = A.tris, E.attrs_in = A.attrs;
+        E.wide = wide_nodes, E.tris_out = wide_tris, E.attrs_out = wide_attrs, E.counters = counters;
+        uint32_t level_n = 1;
+        int cur = 0;
+        while (level_n > 0) {
+            ++wide_depth;
+            E.queue_in = queue[cur], E.queue_out = queue[cur ^ 1], E.n_in = level_n;
+            BUILD_TRY(hipMemsetAsync(counters + 2, 0, sizeof(uint32_t), stream));
+            BUILD_TRY(RT_LAUNCH_CHECKED(k_wide_emit, dim3((level_n + 63u) / 64u), dim3(64), 0, stream, E));
+            uint32_t h_counters[4];
+            BUILD_TRY(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
+            BUILD_TRY(hipStreamSynchronize(stream));
+            level_n = h_counters[2];
+            n_wide = h_counters[0];
+            if (wide_depth > 200u) { // cannot happen (a level always consumes its queue); never spin
+                if (err)
+                    *err = "wide collapse did not terminate";
+                return hipErrorUnknown;
+            }
+            cur ^= 1;
+        }
+    }
+    const auto t3 = std::chrono::steady_clock::now();
+
     guard.keep = true;
+    out->wide = wide_nodes;
+    out->n_wide = n_wide;
+    out->wide_depth = wide_depth;
+    out->wide_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+    if (wide) { // the binary tree and the Morton-ordered records were scaffolding: only the wide tree stays
+        (void)hipFree(A.nodes);
+        (void)hipFree(A.tris);
+        (void)hipFree(A.attrs);
+        A.nodes = nullptr;
+        A.tris = wide_tris;
+        A.attrs = wide_attrs;
+    }
     out->nodes = A.nodes;
     out->tris = A.tris;
     out->attrs = A.attrs;

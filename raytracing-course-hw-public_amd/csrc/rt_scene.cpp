@@ -566,7 +566,9 @@ static int create_impl(const rt_scene_desc *d, const std::shared_ptr<const rt::P
     if (dev_build) {
         // ---- the scene BVH, the triangle records and the shading records are built on the device (rt_bvh_device.hip)
         const char *what = "";
-        hipError_t be = rt::build_bvh_device(d, s->stream, &dbvh, &what);
+        const char *env_hc = std::getenv("RT_WIDE_HOST_COLLAPSE"); // development: collapse the device tree on the host instead
+        const bool device_collapse = wide_build && !(env_hc && std::atoi(env_hc) != 0);
+        hipError_t be = rt::build_bvh_device(d, s->stream, &dbvh, &what, device_collapse, P.wide_cost_node, P.wide_cost_tri);
         if (be != hipSuccess)
             return rt::fail(be == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string("device BVH build: ") + what + ": " + hipGetErrorString(be));
         s->device_built = true;
@@ -576,6 +578,12 @@ static int create_impl(const rt_scene_desc *d, const std::shared_ptr<const rt::P
             s->owned.push_back(dbvh.nodes);
             s->owned.push_back(dbvh.tris);
             s->owned.push_back(dbvh.attrs);
+        } else if (dbvh.wide) {
+            // the whole production build ran on the device (LBVH, dynamic program in the refit, level-by-level emission)
+            s->owned.push_back(dbvh.wide);
+            s->owned.push_back(dbvh.tris);
+            s->owned.push_back(dbvh.attrs);
+            s->wide_ms = dbvh.wide_ms;
         } else {
             // production build on top of the device tree: read it back, collapse on the host, upload the wide tree
             const auto tw0 = std::chrono::steady_clock::now();
@@ -599,15 +607,27 @@ static int create_impl(const rt_scene_desc *d, const std::shared_ptr<const rt::P
             s->wide_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
         }
     }
+    const bool wide_on_device = wide_build && dbvh.wide != nullptr;
     if (wide_build) {
         s->wide_built = true;
-        s->wide_depth = wide->depth;
-        s->wide_cost = wide->sah_cost;
+        s->wide_depth = wide_on_device ? dbvh.wide_depth : wide->depth;
+        s->wide_cost = wide_on_device ? 0.0 : wide->sah_cost;
     }
     DevScene &D = s->dev;
     int rc;
     for (int w = 0; w < 2; ++w) {
         DevBvh &b = w == 0 ? D.scene : D.lights;
+        if (w == 0 && wide_on_device) {
+            b.wide = dbvh.wide;
+            b.tris = dbvh.tris;
+            b.nodes = nullptr;
+            b.root = 0u;
+            b.n_tris = dbvh.n_tris;
+            b.n_wide = dbvh.n_wide;
+            b.fast_ok = 0u;
+            s->dev_n_inner[0] = 0;
+            continue;
+        }
         if (w == 0 && wide_build) {
             if ((rc = upload(wide->nodes, &b.wide, s->owned)) != RT_OK)
                 return rc;
@@ -640,7 +660,7 @@ static int create_impl(const rt_scene_desc *d, const std::shared_ptr<const rt::P
         b.lds_inner = w == 1 ? light_lds_inner(P.flat[w]) : 0u;
         s->dev_n_inner[w] = (uint32_t)P.flat[w].nodes.size();
     }
-    if (dev_build && !wide_build)
+    if (dev_build && (!wide_build || wide_on_device))
         D.attrs = dbvh.attrs;
     else if ((rc = upload(*attrs, &D.attrs, s->owned)) != RT_OK)
         return rc;
@@ -1194,6 +1214,16 @@ extern "C" int rt_build_times(const rt_scene *s, double *build_ms, double *uploa
     if (upload_ms)
         *upload_ms = s->build_upload_ms;
     return RT_OK;
+}
+
+extern "C" int rt_build_times_ex(const rt_scene *s, double *build_ms, double *upload_ms, double *wide_ms) {
+    if (!s)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_build_times_ex: null argument");
+    if (s->group)
+        return rt_build_times_ex(rt::group_primary(s->group), build_ms, upload_ms, wide_ms);
+    if (wide_ms)
+        *wide_ms = s->wide_ms;
+    return rt_build_times(s, build_ms, upload_ms);
 }
 
 // A device-built scene BVH has no host copy: rebuild the reference-style description (pre-order nodes with their OWN box,

@@ -253,6 +253,33 @@ def test_wide_render_matches_oracle(wide_pairs, gpu, name):
     assert np.array_equal(sh.view(np.uint32), full.view(np.uint32))
 
 
+def test_device_collapse_equals_host_collapse_of_the_same_tree(gpu, sg, monkeypatch):
+    """RT_BUILD_WIDE on a device-built tree runs the collapse ON THE DEVICE (dynamic program inside the refit kernel, level-by-level
+    emission). The same LBVH collapsed by wide_build.cpp on the host (RT_WIDE_HOST_COLLAPSE=1) must give the same tree up to
+    float-vs-double ties in the cost comparisons: same triangles, (almost) the same node count, depth and leaf-size histogram."""
+    from test_wide_build import decode, walk_and_check
+
+    sc = sg.room_scene(30000, seed=8, n_lights=4, n_materials=8, tex_size=0, offset=0.1)
+    dev = gpu.DeviceScene(sc, wide=True, device_bvh=True)
+    d1 = dev.bvh_wide_dump()
+    t1 = dev.build_times()
+    dev.close()
+    monkeypatch.setenv("RT_WIDE_HOST_COLLAPSE", "1")
+    dev = gpu.DeviceScene(sc, wide=True, device_bvh=True)
+    d2 = dev.bvh_wide_dump()
+    t2 = dev.build_times()
+    dev.close()
+    monkeypatch.delenv("RT_WIDE_HOST_COLLAPSE")
+    depth1, hist1 = walk_and_check(d1["nodes"], d1["tris"][:, 9].copy(), sc.positions)
+    depth2, hist2 = walk_and_check(d2["nodes"], d2["tris"][:, 9].copy(), sc.positions)
+    n1, n2 = len(d1["nodes"]), len(d2["nodes"])
+    print(f"device collapse: {n1} nodes, depth {depth1}, leaf slots {hist1}, {t1['wide_ms']:.2f} ms; host collapse: {n2} nodes, depth {depth2}, leaf slots {hist2}, {t2['wide_ms']:.1f} ms")
+    assert abs(n1 - n2) <= 0.01 * n2 and abs(depth1 - depth2) <= 1
+    for k in (1, 2, 3):
+        assert abs(hist1.get(k, 0) - hist2.get(k, 0)) <= 0.02 * sum(hist2.values())
+    assert t1["wide_ms"] < t2["wide_ms"]
+
+
 def test_wide_refuses_the_parity_modes(wide_pairs, gpu):
     devh = wide_pairs["room_plain"][0]
     with pytest.raises(gpu.RtError) as e:
