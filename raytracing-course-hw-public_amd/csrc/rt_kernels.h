@@ -60,7 +60,8 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
 hipError_t launch_wavefront_cast(const DevScene &S, WfLaunch L, const float *rays, uint32_t n, bool packet, bool stats, uint32_t *prim, float *bct,
                                  hipStream_t stream);
 // rt_wide.hip: the closest-hit kernel of scenes built with RT_BUILD_WIDE (same queue protocol as wf_extend)
-hipError_t launch_extend_wide(const DevScene &S, const WfLaunch &L, bool stats, int blocks, hipStream_t stream);
+// `packet`: the wave walks the tree once for its 64 consecutive rays (coherent primary rays), records through the scalar cache
+hipError_t launch_extend_wide(const DevScene &S, const WfLaunch &L, bool packet, bool stats, int blocks, hipStream_t stream);
 // bytes of temporary storage rocPRIM's radix sort needs for `n` (key, slot) pairs
 size_t wavefront_sort_temp_bytes(size_t n);
 } // namespace rt

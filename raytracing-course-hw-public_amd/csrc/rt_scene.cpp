@@ -919,7 +919,12 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
             s->wf_count_events.push_back(ev);
         }
         rt::WfHostSync hsync{s->wf_host_count, s->wf_count_events.data(), (int)s->wf_count_events.size()};
-        W.sort_mode = sort_env ? (uint32_t)std::atoi(sort_env) : 4u; // 24-bit key: cell, octant, direction sub-cone (measured best)
+        // Coherence sort of bounces >= 1 (24-bit key: cell, octant, direction sub-cone: measured best). It pays where node fetches
+        // miss the caches; a WIDE tree that fits them gains nothing from it and loses the sort's own time (S-sponza, 15 MB of
+        // nodes + triangles: 436 vs 409 Msamples/s without / with; S-10M, 0.7 GB: 196 vs 220; profiles/r03_wide.txt).
+        const size_t bvh_bytes = (size_t)s->dev.scene.n_wide * sizeof(WideNode) + (size_t)s->dev.scene.n_tris * sizeof(DevTri);
+        const uint32_t sort_default = (s->wide_built && bvh_bytes < ((size_t)128 << 20)) ? 0u : 4u;
+        W.sort_mode = sort_env ? (uint32_t)std::atoi(sort_env) : sort_default;
         // production traversal: global-best pruning (rt_abi.h RT_FLAG_GLOBAL_BEST; RT_TRAVERSAL=global for callers without flags)
         const char *trav_env = std::getenv("RT_TRAVERSAL");
         W.global_best = ((p->flags & RT_FLAG_GLOBAL_BEST) || (trav_env && !std::strcmp(trav_env, "global"))) ? 1u : 0u;

@@ -767,7 +767,7 @@ namespace rt {
 // reference's traversal order (near-local pruning, the parity mode) or with global-best pruning (L.global_best, production)
 static hipError_t launch_extend(const DevScene &S, const WfLaunch &L, bool packet, bool stats, int ext_blocks, hipStream_t stream) {
     if (S.scene.wide) // production build (RT_BUILD_WIDE): every bounce walks the 8-wide tree (rt_wide.hip)
-        return launch_extend_wide(S, L, stats, ext_blocks, stream);
+        return launch_extend_wide(S, L, packet, stats, ext_blocks, stream);
     const dim3 grid(ext_blocks), block(256);
     const bool gb = L.global_best != 0u;
 #define EXT_CASE(P, ST, G)                                                                          \

@@ -70,6 +70,54 @@ DEV void wide_init(WTrav &T, const DevBvh &bvh, V3 o, V3 d, V3 r) {
 
 DEV float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u); } // v_cvt_f32_ubyteK
 
+// The eight slab tests of one node record against one ray: bit i of the result = the ray meets slot i's box within [EPS, tlim].
+// t = q * ad + b stands for ((p + q * cell) - o) / d. Error margin: the two products and the sum are each rounded once
+// (<= 3 half-ulps of the larger magnitude), 1/d itself is off by half an ulp: 2^-21 of (|b| + 255 |ad|) covers it 4x over.
+DEV uint32_t wide_test8(const uint4 n0, const uint4 n2, const uint4 n3, const uint4 n4, V3 o, V3 idir, float tlim) {
+    const uint32_t ew = n0.w;
+    const float adx = __uint_as_float((ew & 255u) << 23) * idir.x, ady = __uint_as_float(((ew >> 8) & 255u) << 23) * idir.y,
+                adz = __uint_as_float(((ew >> 16) & 255u) << 23) * idir.z;
+    const float bx = (__uint_as_float(n0.x) - o.x) * idir.x, by = (__uint_as_float(n0.y) - o.y) * idir.y, bz = (__uint_as_float(n0.z) - o.z) * idir.z;
+    const float ex = __builtin_fmaf(255.0f, __builtin_fabsf(adx), __builtin_fabsf(bx)) * 4.76837158203125e-07f,
+                ey = __builtin_fmaf(255.0f, __builtin_fabsf(ady), __builtin_fabsf(by)) * 4.76837158203125e-07f,
+                ez = __builtin_fmaf(255.0f, __builtin_fabsf(adz), __builtin_fabsf(bz)) * 4.76837158203125e-07f;
+    const float bx0 = bx - ex, bx1 = bx + ex, by0 = by - ey, by1 = by + ey, bz0 = bz - ez, bz1 = bz + ez;
+    // near / far planes per axis by the direction sign: words {slots 0..3, slots 4..7}
+    const bool nx = idir.x < 0.0f, ny = idir.y < 0.0f, nz = idir.z < 0.0f;
+    const uint32_t xn0 = nx ? n3.z : n2.x, xn1 = nx ? n3.w : n2.y, xf0 = nx ? n2.x : n3.z, xf1 = nx ? n2.y : n3.w;
+    const uint32_t yn0 = ny ? n4.x : n2.z, yn1 = ny ? n4.y : n2.w, yf0 = ny ? n2.z : n4.x, yf1 = ny ? n2.w : n4.y;
+    const uint32_t zn0 = nz ? n4.z : n3.x, zn1 = nz ? n4.w : n3.y, zf0 = nz ? n3.x : n4.z, zf1 = nz ? n3.y : n4.w;
+    uint32_t h = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = i & 3;
+        const uint32_t wxn = i < 4 ? xn0 : xn1, wxf = i < 4 ? xf0 : xf1, wyn = i < 4 ? yn0 : yn1, wyf = i < 4 ? yf0 : yf1, wzn = i < 4 ? zn0 : zn1, wzf = i < 4 ? zf0 : zf1;
+        const float tx0 = __builtin_fmaf(ub(wxn, k), adx, bx0), ty0 = __builtin_fmaf(ub(wyn, k), ady, by0), tz0 = __builtin_fmaf(ub(wzn, k), adz, bz0);
+        const float tx1 = __builtin_fmaf(ub(wxf, k), adx, bx1), ty1 = __builtin_fmaf(ub(wyf, k), ady, by1), tz1 = __builtin_fmaf(ub(wzf, k), adz, bz1);
+        const float tmin = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, EPS));
+        const float tmax = fminf(fminf(tx1, ty1), fminf(tz1, tlim));
+        h |= tmin <= tmax ? (1u << i) : 0u;
+    }
+    return h;
+}
+// inner-slot hits -> priority bits (slot ^ oct_inv): an xor of the bit INDEX = three conditional block swaps of the byte
+DEV uint32_t wide_priority(uint32_t r, uint32_t oct_inv) {
+    const uint32_t s1 = ((r & 0x55u) << 1) | ((r >> 1) & 0x55u);
+    r = (oct_inv & 1u) ? s1 : r;
+    const uint32_t s2 = ((r & 0x33u) << 2) | ((r >> 2) & 0x33u);
+    r = (oct_inv & 2u) ? s2 : r;
+    const uint32_t s4 = ((r & 0x0Fu) << 4) | (r >> 4);
+    return (oct_inv & 4u) ? s4 : r;
+}
+// leaf-slot hits -> their triangles: every bit of the slot mask tripled, then only the triangles that exist
+DEV uint32_t wide_leaf_tris(uint32_t l, uint32_t tri_mask) {
+    l &= 255u;
+    l = (l | (l << 8)) & 0x0000F00Fu;
+    l = (l | (l << 4)) & 0x000C30C3u;
+    l = (l | (l << 2)) & 0x00249249u;
+    return (l * 7u) & tri_mask;
+}
+
 // One node visit: take the next child of the current group (pushing the rest back if any), fetch its record and test its
 // eight boxes against [EPS, best.t]. Leaves the child's own group in (gx, gy) and its hit triangles in (tbase, tm, tall).
 template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const WideNode *nodes, STK &stk, LaneStats<STATS> &st) {
@@ -89,65 +137,16 @@ template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const WideNod
     const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
     st.node();
     st.box(8);
-    const uint32_t ew = n0.w, imask = ew >> 24;
-    const float adx = __uint_as_float((ew & 255u) << 23) * T.idir.x, ady = __uint_as_float(((ew >> 8) & 255u) << 23) * T.idir.y,
-                adz = __uint_as_float(((ew >> 16) & 255u) << 23) * T.idir.z;
-    const float bx = (__uint_as_float(n0.x) - T.o.x) * T.idir.x, by = (__uint_as_float(n0.y) - T.o.y) * T.idir.y, bz = (__uint_as_float(n0.z) - T.o.z) * T.idir.z;
-    // t = q * ad + b stands for ((p + q * cell) - o) / d. Error margin: the two products and the sum are each rounded once
-    // (<= 3 half-ulps of the larger magnitude), 1/d itself is off by half an ulp: 2^-21 of (|b| + 255 |ad|) covers it 4x over.
-    const float ex = __builtin_fmaf(255.0f, __builtin_fabsf(adx), __builtin_fabsf(bx)) * 4.76837158203125e-07f,
-                ey = __builtin_fmaf(255.0f, __builtin_fabsf(ady), __builtin_fabsf(by)) * 4.76837158203125e-07f,
-                ez = __builtin_fmaf(255.0f, __builtin_fabsf(adz), __builtin_fabsf(bz)) * 4.76837158203125e-07f;
-    const float bx0 = bx - ex, bx1 = bx + ex, by0 = by - ey, by1 = by + ey, bz0 = bz - ez, bz1 = bz + ez;
-    // near / far planes per axis by the direction sign: words {slots 0..3, slots 4..7}
-    const bool nx = T.idir.x < 0.0f, ny = T.idir.y < 0.0f, nz = T.idir.z < 0.0f;
-    const uint32_t xn0 = nx ? n3.z : n2.x, xn1 = nx ? n3.w : n2.y, xf0 = nx ? n2.x : n3.z, xf1 = nx ? n2.y : n3.w;
-    const uint32_t yn0 = ny ? n4.x : n2.z, yn1 = ny ? n4.y : n2.w, yf0 = ny ? n2.z : n4.x, yf1 = ny ? n2.w : n4.y;
-    const uint32_t zn0 = nz ? n4.z : n3.x, zn1 = nz ? n4.w : n3.y, zf0 = nz ? n3.x : n4.z, zf1 = nz ? n3.y : n4.w;
-    const float tlim = T.best.t;
-    uint32_t h = 0u;
-#ifdef RT_WIDE_DIAG
-    bool diag_any_geo = false;
-#endif
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int k = i & 3;
-        const uint32_t wxn = i < 4 ? xn0 : xn1, wxf = i < 4 ? xf0 : xf1, wyn = i < 4 ? yn0 : yn1, wyf = i < 4 ? yf0 : yf1, wzn = i < 4 ? zn0 : zn1, wzf = i < 4 ? zf0 : zf1;
-        const float tx0 = __builtin_fmaf(ub(wxn, k), adx, bx0), ty0 = __builtin_fmaf(ub(wyn, k), ady, by0), tz0 = __builtin_fmaf(ub(wzn, k), adz, bz0);
-        const float tx1 = __builtin_fmaf(ub(wxf, k), adx, bx1), ty1 = __builtin_fmaf(ub(wyf, k), ady, by1), tz1 = __builtin_fmaf(ub(wzf, k), adz, bz1);
-        const float tmin = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, EPS));
-        const float tmax = fminf(fminf(tx1, ty1), fminf(tz1, tlim));
-        h |= tmin <= tmax ? (1u << i) : 0u;
-#ifdef RT_WIDE_DIAG
-        if (tmin <= fminf(fminf(tx1, ty1), tz1))
-            diag_any_geo = true; // the ray meets this box somewhere, whatever the best hit says
-#endif
-    }
-    // inner slots -> priority bits (slot ^ oct_inv): an xor of the bit INDEX = three conditional block swaps of the byte
-    uint32_t r = h & imask;
-    {
-        const uint32_t s1 = ((r & 0x55u) << 1) | ((r >> 1) & 0x55u);
-        r = (T.oct_inv & 1u) ? s1 : r;
-        const uint32_t s2 = ((r & 0x33u) << 2) | ((r >> 2) & 0x33u);
-        r = (T.oct_inv & 2u) ? s2 : r;
-        const uint32_t s4 = ((r & 0x0Fu) << 4) | (r >> 4);
-        r = (T.oct_inv & 4u) ? s4 : r;
-    }
+    const uint32_t imask = n0.w >> 24;
+    const uint32_t h = wide_test8(n0, n2, n3, n4, T.o, T.idir, T.best.t);
     T.gx = n1.x;
-    T.gy = (r << 24) | imask;
-    // leaf slots -> their triangles: every bit of the slot mask tripled, then only the triangles that exist
-    uint32_t l = h & ~imask & 255u;
-    l = (l | (l << 8)) & 0x0000F00Fu;
-    l = (l | (l << 4)) & 0x000C30C3u;
-    l = (l | (l << 2)) & 0x00249249u;
+    T.gy = (wide_priority(h & imask, T.oct_inv) << 24) | imask;
     T.tbase = n1.y;
     T.tall = n1.z;
-    T.tm = (l * 7u) & n1.z;
+    T.tm = wide_leaf_tris(h & ~imask, n1.z);
 #ifdef RT_WIDE_DIAG // development census through the (otherwise idle) light counters of the instrumented variant
     if (h == 0u)
         st.lhit(); // a visit that hit none of the eight boxes
-    if (h == 0u && diag_any_geo)
-        st.lq(); // ... of which: only because the best hit is already closer (a distance-aware stack would have skipped the visit)
     st.lbox((uint32_t)__popc(h & imask)); // inner children hit
     st.ltri();                            // (visits, again: denominator)
     if ((h & ~imask & 255u) != 0u)
@@ -320,11 +319,134 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) 
     st.flush(L.stats);
 }
 
+// ------------------------------------------------------------------------------------------------ coherent packets
+// Primary rays: a wave's 64 queue positions are 64 samples of one pixel (or of a few neighbours), rays that walk the same nodes.
+// Here the wave walks the tree ONCE for all of them: the pending-group stack is wave-uniform (LDS, one column per wave), every
+// node and triangle record is fetched once through the scalar cache, each lane tests the eight boxes / the triangle against
+// its OWN ray and best hit, and the wave descends into a child when ANY lane hit it (front to back by the first lane's
+// direction signs). A lane tests a triangle only if its own ray met that leaf slot's box, as in the per-lane kernel; its
+// closest hit is therefore the same (it may see boxes the per-lane walk would have culled earlier, never fewer).
+// No vector loads, no divergence between node and triangle work: it pays while the 64 rays stay together (the kernel counts
+// node visits and the lanes that met the node; the host drops it for a configuration whose packets fall apart).
+#ifndef RT_WIDE_PKT_CHUNK
+#define RT_WIDE_PKT_CHUNK 256u
+#endif
+template <bool STATS> __global__ __launch_bounds__(256, 8) void wf_extend_wide_packet(const DevScene S, const WfLaunch L) {
+    __shared__ uint2 s_stack_all[4][RT_MAX_STACK + 1]; // one pending group per level of the tree at most (depth <= RT_MAX_STACK)
+    uint2 *s_stack = s_stack_all[threadIdx.x >> 6];
+    LaneStats<STATS> st;
+    const uint32_t n_in = L.counters[WF_CNT_IN];
+    const uint32_t lane = threadIdx.x & 63u;
+    const WideNode *nodes = S.scene.wide;
+    unsigned long long n_trips = 0ull, n_lanes = 0ull; // wave-uniform
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0u)
+            base = atomicAdd(L.counters + WF_CNT_TICKET, (uint32_t)RT_WIDE_PKT_CHUNK);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n_in)
+            break;
+        for (uint32_t q0 = base; q0 < base + RT_WIDE_PKT_CHUNK && q0 < n_in; q0 += 64u) { // wave-uniform
+            const uint32_t jq = q0 + lane;
+            const bool have = jq < n_in;
+            V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f), idir = mk(1.f, 1.f, 1.f);
+            Hit best = Hit{RT_NONE, 0.f, 0.f, -RT_INF}; // a lane without a ray: an empty [EPS, -inf] range meets no box
+            if (have) {
+                const uint32_t j = L.order ? L.order[jq] : jq;
+                const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
+                const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
+                WTrav T;
+                wide_init(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r2.x, r2.y, r2.z));
+                o = T.o, d = T.d, idir = T.idir;
+                best.t = RT_INF;
+            }
+            const uint32_t oct = (idir.x < 0.0f ? 1u : 0u) | (idir.y < 0.0f ? 2u : 0u) | (idir.z < 0.0f ? 4u : 0u);
+            const uint32_t oct_inv = 7u ^ (uint32_t)__builtin_amdgcn_readfirstlane((int)oct); // lane 0 of the packet always has a ray
+            uint32_t gx = 0u, gy = S.scene.n_wide != 0u ? 0x80000000u : 0u; // wave-uniform
+            int sp = 0;
+            for (;;) {
+                if ((gy >> 24) == 0u) {
+                    if (sp == 0)
+                        break;
+                    --sp;
+                    const uint2 g = s_stack[sp];
+                    gx = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.x);
+                    gy = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.y);
+                    continue;
+                }
+                const uint32_t bit = 31u - (uint32_t)__clz((int)gy);
+                const uint32_t rest = gy ^ (1u << bit);
+                const uint32_t slot = (bit - 24u) ^ oct_inv;
+                uint32_t idx = gx + (uint32_t)__popc(gy & 0xFFu & ((1u << slot) - 1u));
+                if ((rest >> 24) != 0u && sp < RT_MAX_STACK) {
+                    if (lane == 0u)
+                        s_stack[sp] = make_uint2(gx, rest);
+                    ++sp;
+                }
+                idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx); // the record's address is scalar: one s_load per piece for the whole wave
+                typedef uint32_t U4v __attribute__((ext_vector_type(4)));
+                typedef const __attribute__((address_space(4))) U4v *ConstU4;
+                ConstU4 p = (ConstU4)(unsigned long long)(nodes + idx);
+                const U4v v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3], v4 = p[4];
+                const uint4 n0 = make_uint4(v0.x, v0.y, v0.z, v0.w), n1 = make_uint4(v1.x, v1.y, v1.z, v1.w), n2 = make_uint4(v2.x, v2.y, v2.z, v2.w),
+                            n3 = make_uint4(v3.x, v3.y, v3.z, v3.w), n4 = make_uint4(v4.x, v4.y, v4.z, v4.w);
+                const uint32_t imask = n0.w >> 24;
+                const uint32_t h = wide_test8(n0, n2, n3, n4, o, idir, best.t);
+                if (have) {
+                    st.node();
+                    st.box(8);
+                }
+                uint32_t H = 0u; // slots ANY lane hit
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    H |= __ballot((h >> i) & 1u) != 0ull ? (1u << i) : 0u;
+                ++n_trips;
+                n_lanes += (uint32_t)__popcll(__ballot(h != 0u));
+                gx = n1.x;
+                gy = (wide_priority(H & imask, oct_inv) << 24) | imask;
+                // triangles of the leaf slots some lane met, in record order; a lane tests those of the slots IT met
+                uint32_t tm = wide_leaf_tris(H & ~imask, n1.z);
+                const uint32_t tall = n1.z, tbase = n1.y;
+                while (tm != 0u) {
+                    const uint32_t b = (uint32_t)__ffs((int)tm) - 1u;
+                    tm &= tm - 1u;
+                    uint32_t k = tbase + (uint32_t)__popc(tall & ((1u << b) - 1u));
+                    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                    ConstF4 tp = as_const_f4(S.scene.tris + k);
+                    const F4v r0 = tp[0], r1 = tp[1], r2 = tp[2];
+                    if ((h >> (b / 3u)) & 1u) {
+                        st.tri();
+                        V3 xs;
+                        if (tri_hit(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), o, d, EPS, xs) && best.t > xs.z) {
+                            best.k = k;
+                            best.b = xs.x;
+                            best.c = xs.y;
+                            best.t = xs.z;
+                        }
+                    }
+                }
+            }
+            if (have)
+                *reinterpret_cast<float4 *>(L.hits + jq) = make_float4(__uint_as_float(best.k), best.b, best.c, best.k == RT_NONE ? 0.0f : best.t);
+        }
+    }
+    if (lane == 0u && L.packet_census && n_trips != 0ull) {
+        atomicAdd(L.packet_census, n_trips);
+        atomicAdd(L.packet_census + 1, n_lanes);
+    }
+    st.flush(L.stats);
+}
+
 } // namespace
 
 namespace rt {
 
-hipError_t launch_extend_wide(const DevScene &S, const WfLaunch &L, bool stats, int blocks, hipStream_t stream) {
+hipError_t launch_extend_wide(const DevScene &S, const WfLaunch &L, bool packet, bool stats, int blocks, hipStream_t stream) {
+    if (packet) {
+        if (stats)
+            return RT_LAUNCH_CHECKED((wf_extend_wide_packet<true>), dim3(blocks), dim3(256), 0, stream, S, L);
+        return RT_LAUNCH_CHECKED((wf_extend_wide_packet<false>), dim3(blocks), dim3(256), 0, stream, S, L);
+    }
     if (stats)
         return RT_LAUNCH_CHECKED((wf_extend_wide<true>), dim3(blocks), dim3(256), 0, stream, S, L);
     return RT_LAUNCH_CHECKED((wf_extend_wide<false>), dim3(blocks), dim3(256), 0, stream, S, L);

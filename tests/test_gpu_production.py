@@ -194,6 +194,13 @@ def test_wide_hits_equal_the_oracle(wide_pairs, gpu, name):
         assert st["nodes_visited"] > 0 and st["box_tests"] == 8 * st["nodes_visited"]
         gp2, gb2 = dev.cast_rays(rays)  # the plain probe entry point is routed through the same kernel on a wide scene
         assert np.array_equal(gp2, gp) and np.array_equal(gb2.view(np.uint32), gb.view(np.uint32))
+        # the packet kernel (one walk per 64 consecutive rays, records through the scalar cache): coherent camera rays and, as a
+        # stress, incoherent random ones; same superset contract, and the same hits as the per-lane kernel wherever no tie is involved
+        pp, pb, pst = dev.cast_rays_ex(rays, gpu.RT_CAST_PACKET)
+        pties, pcloser = compare_superset_hits_with_oracle(op, ob, pp, pb, f"{name}, wide packets, {what}")
+        assert pties + pcloser <= len(rays) // 500 + (40 if name == "boxes" else 0), (name, what, pties, pcloser)
+        assert np.array_equal(pb[:, 2].view(np.uint32), gb[:, 2].view(np.uint32)), "packet and per-lane wide traversal disagree on a closest-hit distance"
+        assert pst["tri_tests"] > 0 and pst["nodes_visited"] >= st["nodes_visited"]  # a packet visits the union of its rays' nodes
 
 
 def test_wide_degenerate_rays(wide_pairs, gpu):
