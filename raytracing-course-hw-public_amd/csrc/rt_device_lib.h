@@ -895,10 +895,17 @@ DEV C4 tex_sample(const DevScene &S, int32_t tex, int dflt, float u, float v, bo
     } else {
         // wrap_repeat rounded up to 1.0f: the reference indexes row-major position x + y*w past the row / the image
         // (geometry.h:556-563); as in the oracle the flat index is clamped for memory safety only, then located
-        const int last = (int)T.count - 1;
+        // Located WITHOUT an integer division (its expansion was the kernel's register-pressure peak, on a path almost no
+        // lookup takes): here 0 <= x <= w + 1 and 0 <= y <= h + 1, so the flat index i = x + y * w lies in row y + x / w with
+        // x / w in {0, 1, 2}, and an index beyond the last texel is the last texel (w - 1, h - 1).
         auto flat = [&](int x, int y) {
-            const int i = min(max(x + y * w, 0), last);
-            return at(i % w, i / w);
+            const int over = x >= 2 * w ? 2 : (x >= w ? 1 : 0);
+            int row = y + over, col = x - over * w;
+            if (row >= h) { // i > last
+                row = h - 1;
+                col = w - 1;
+            }
+            return at(col, row);
         };
         q00 = flat(x0, y0), q01 = flat(x0, y1), q10 = flat(x1, y0), q11 = flat(x1, y1);
     }
@@ -951,13 +958,15 @@ DEV Surf make_surf(const DevScene &S, const Hit &h, V3 ro, V3 rd, const float *s
         for (int i = 0; i < 7; ++i)
             q[i] = p[i];
     }
+    // The material record is read in two halves: the texture slots and scalar factors now, colour / emission / roughness only
+    // AFTER the four texture lookups (their registers would otherwise sit idle through the kernel's register-pressure peak).
+    // The second read hits the line the first one brought in.
     DevMaterial m;
+    const float4 *mat_p = reinterpret_cast<const float4 *>(S.materials + at.material);
     {
-        const float4 *p = reinterpret_cast<const float4 *>(S.materials + at.material);
         float4 *q = reinterpret_cast<float4 *>(&m);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            q[i] = p[i];
+        q[2] = mat_p[2];
+        q[3] = mat_p[3];
     }
     SD_STAMP(SD_ATTR);
     const float b = h.b, c = h.c;
@@ -979,6 +988,12 @@ DEV Surf make_surf(const DevScene &S, const Hit &h, V3 ro, V3 rd, const float *s
     C4 et = tex_sample(S, m.emissive_tex, TEX_DEFAULT_WHITE, tu, tv, true, s_lin, s_gam, st); // :619-621
     st.shaded();
     SD_STAMP(SD_TEX);
+    {
+        asm volatile("" : "+v"(mat_p)); // not before this point
+        float4 *q = reinterpret_cast<float4 *>(&m);
+        q[0] = mat_p[0];
+        q[1] = mat_p[1];
+    }
     Surf s;
     s.normal = is_inside ? -normal : normal;
     s.shading_normal = is_inside ? -shading : shading;
