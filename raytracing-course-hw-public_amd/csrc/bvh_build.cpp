@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <future>
@@ -243,17 +244,48 @@ FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions) {
         t.flags = 0;
         t.pad = 0;
     }
-    // inner nodes get device indices in pre-order among inner nodes
+    // inner nodes get device indices in pre-order among inner nodes (RT_NODE_ORDER, development: 1 = breadth first,
+    // 2 = sibling pairs: a node's two inner children adjacent, subtrees depth first)
     std::vector<uint32_t> dev_index(bvh.nodes.size(), RT_NONE);
     uint32_t n_inner = 0;
+    auto is_inner = [&](uint32_t i) { return bvh.nodes[i].left != RT_NONE || bvh.nodes[i].right != RT_NONE; };
     for (size_t i = 0; i < bvh.nodes.size(); ++i) {
         const HostNode &nd = bvh.nodes[i];
-        if (nd.left != RT_NONE || nd.right != RT_NONE)
-            dev_index[i] = n_inner++;
-        else if (nd.obj_end > nd.obj_begin) {
+        if (!is_inner((uint32_t)i) && nd.obj_end > nd.obj_begin) {
             f.tris[nd.obj_end - 1].flags |= 1u; // last triangle of its leaf
             f.tris[nd.obj_begin].flags |= 2u;   // first triangle of its leaf
         }
+    }
+    const char *order_env = std::getenv("RT_NODE_ORDER");
+    const int order_mode = order_env ? std::atoi(order_env) : 0;
+    if (order_mode == 1 && is_inner(bvh.root)) {
+        std::vector<uint32_t> q{bvh.root};
+        for (size_t h = 0; h < q.size(); ++h) {
+            dev_index[q[h]] = n_inner++;
+            for (uint32_t c : {bvh.nodes[q[h]].left, bvh.nodes[q[h]].right})
+                if (is_inner(c))
+                    q.push_back(c);
+        }
+    } else if (order_mode == 2 && is_inner(bvh.root)) {
+        dev_index[bvh.root] = n_inner++;
+        std::vector<uint32_t> st{bvh.root};
+        while (!st.empty()) {
+            const uint32_t i = st.back();
+            st.pop_back();
+            const uint32_t l = bvh.nodes[i].left, r = bvh.nodes[i].right;
+            if (is_inner(l))
+                dev_index[l] = n_inner++;
+            if (is_inner(r))
+                dev_index[r] = n_inner++;
+            if (is_inner(r))
+                st.push_back(r);
+            if (is_inner(l))
+                st.push_back(l);
+        }
+    } else {
+        for (size_t i = 0; i < bvh.nodes.size(); ++i)
+            if (is_inner((uint32_t)i))
+                dev_index[i] = n_inner++;
     }
     auto ref_of = [&](uint32_t node) -> uint32_t {
         const HostNode &nd = bvh.nodes[node];

@@ -13,7 +13,8 @@ export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; mkdir -p $O
 id=$wl; [ "$mode" = wide ] && id=$wl-wide; [ "$mode" = global ] && id=$wl-gbest
 if [ "$wl" = s10m ]; then pmc_spp=8; else pmc_spp=16; fi
 extra="--workload $wl --mode $mode --no-extras"
-python3 $R/bench.py $extra > $O/${tag}_bench_$id.json 2> $O/${tag}_bench_$id.err; echo "bench exit $?"; tail -c 1500 $O/${tag}_bench_$id.json
+cpu=""; { [ "$wl" = s10m ] || [ "$mode" != parity ]; } && cpu="--no-cpu-baseline"  # the CPU leg is on the default bench line (S-sponza, parity)
+python3 $R/bench.py $extra $cpu > $O/${tag}_bench_$id.json 2> $O/${tag}_bench_$id.err; echo "bench exit $?"; tail -c 1500 $O/${tag}_bench_$id.json
 cd /tmp
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats_$id -- python3 $R/bench.py $extra --no-cpu-baseline > $O/${tag}_stats_$id.log 2>&1; echo "stats pass exit $?"
 for c in FETCH_SIZE WRITE_SIZE; do
