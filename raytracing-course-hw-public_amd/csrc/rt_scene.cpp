@@ -51,6 +51,9 @@ template <class T> int upload(const std::vector<T> &v, const T **out, std::vecto
 
 // wf_advance scans the sub-queue fill levels with ONE wave (a lane per sub-queue) and wf_sort_keys finds a ray's sub-queue with
 // a power-of-two binary search (rt_wavefront.hip)
+#ifndef RT_WIDE_PACKET_MIN_LANES
+#define RT_WIDE_PACKET_MIN_LANES 20.0 /* the wide packet kernel wins from 27 lanes per trip (4 SPP per pass) upwards: tools/packet_calibration.py */
+#endif
 static_assert(WF_STRIPES == 64u && (WF_STRIPES & (WF_STRIPES - 1u)) == 0u, "WF_STRIPES must equal the wave size (64)");
 
 // device allocation that is released on every return path of the probe entry points
@@ -165,6 +168,7 @@ struct rt_scene {
     // (lanes served per trip) decides per configuration whether later passes and renders keep using it
     uint64_t pkt_key = 0; // width, height, samples per pass, shard count of the configuration pkt_off was measured on
     bool pkt_off = false;
+    uint32_t pkt_lanes_x100 = 0; // last packet census: lanes served per trip x 100 (rt_stats.reserved)
 
     int ensure_wavefront(uint64_t paths, uint64_t pixels, uint32_t depth) {
         if (paths <= wf_paths_cap && pixels <= wf_pixels_cap && depth <= wf_depth_cap)
@@ -946,12 +950,20 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
                     s->pkt_key = key;
                     s->pkt_off = false;
                 }
-                W.use_packet = pkt_mode == 0 ? 0u : pkt_mode > 0 ? 1u : (W.pass_samples >= 16u && !s->pkt_off) ? 1u : 0u;
+                const uint32_t pkt_min_spp = s->wide_built ? 4u : 16u; // measured break-even of the two packet kernels
+                W.use_packet = pkt_mode == 0 ? 0u : pkt_mode > 0 ? 1u : (W.pass_samples >= pkt_min_spp && !s->pkt_off) ? 1u : 0u;
                 unsigned long long census[2] = {0ull, 0ull};
                 HIP_TRY(rt::launch_wavefront_pass(s->dev, W, counters, s->num_cus, s0 == 0, s0 + W.pass_samples >= p->samples, s->stream,
                                                   stats ? &s->ext_events : nullptr, census, s->wf_host_count ? &hsync : nullptr));
-                if (census[0] != 0ull && (double)census[1] < 33.0 * (double)census[0])
-                    s->pkt_off = true;
+                // lanes served per packet trip below which the per-lane kernel is faster: 33 for wf_extend_packet (profiles/r02_packet.txt);
+                // RT_WF_PACKET_MIN overrides it (development). The wide packet kernel's break-even is lower (profiles/r03_wide.txt).
+                static const double min_lanes_env = std::getenv("RT_WF_PACKET_MIN") ? std::atof(std::getenv("RT_WF_PACKET_MIN")) : -1.0;
+                const double min_lanes = min_lanes_env >= 0.0 ? min_lanes_env : (s->wide_built ? RT_WIDE_PACKET_MIN_LANES : 33.0);
+                if (census[0] != 0ull) {
+                    s->pkt_lanes_x100 = (uint32_t)(100.0 * (double)census[1] / (double)census[0]);
+                    if ((double)census[1] < min_lanes * (double)census[0])
+                        s->pkt_off = true;
+                }
             }
         }
     } else if (L.n_items > 0) {
@@ -1011,6 +1023,7 @@ static int render_impl(rt_scene *s, const rt_params *p, float *fb_rgb, uint8_t *
                 stats->dominant_ms += t;
         }
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        stats->reserved = wavefront ? s->pkt_lanes_x100 : 0u; // development: the packet kernel's census (lanes served per trip x 100; 0 = it did not run)
     }
     return RT_OK;
 }
