@@ -203,7 +203,7 @@ class Runner:
         self.wl_name, self.mode, self.m = wl_name, mode, MODES[mode]
         self.W, self.H, self.spp, self.n_pix = W, H, spp, W * H
         self.launcher, self.rank, self.world, self.n_gpus, self.backend, self.film = launcher, rank, world, n_gpus, backend, film
-        self.workload_id = (wl_name if full_size is True else f"{wl_name}-{full_size}" if full_size else f"{wl_name}-custom") + ("-lbvh" if device_bvh else "") + self.m["suffix"]
+        self.workload_id = (wl_name if full_size is True else f"{wl_name}-{full_size}" if full_size else f"{wl_name}-custom") + ("-dev" if device_bvh else "") + self.m["suffix"]
         self.device = torch.device("cuda", local_rank)
         t0 = time.time()
         dev_arg = list(range(n_gpus)) if launcher == "group" else local_rank
@@ -387,7 +387,7 @@ def main() -> None:
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"], help="strong = BASELINE config 4 (1000 SPP in all); auto: strong at 8 GPUs, weak otherwise")
     ap.add_argument("--mode", default="parity", choices=sorted(MODES), help="traversal mode of the HEADLINE value (default parity; the others are reported under 'production')")
     ap.add_argument("--bvh", default="reference", choices=["reference", "device"],
-                    help="binary builder: reference = host build in the reference's exact topology (the parity tree); device = LBVH built on the GPU (rt_bvh_device.hip). "
+                    help="binary builder: reference = host build in the reference's exact topology (the parity tree); device = built on the GPU (rt_bvh_device.hip: PLOC, or the radix-tree LBVH with RT_DEVICE_BUILDER=lbvh). "
                          "--mode wide collapses whichever is chosen")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -452,10 +452,12 @@ def main() -> None:
         for mode in ("global", "wide"):
             if mode == skip:
                 continue
-            r = Runner(rt, torch, dist, scene_, wl_name_, mode, W_, H_, spp_, full_size=full_, **common)
+            # the wide record is the FULL production build: binary tree (PLOC) and collapse on the device; global-best keeps the parity tree
+            kw = dict(common, device_bvh=True) if mode == "wide" else common
+            r = Runner(rt, torch, dist, scene_, wl_name_, mode, W_, H_, spp_, full_size=full_, **kw)
             v = r.timed(steps_, warm_)
             rf = r.roofline()
-            out[mode] = {"traversal": MODES[mode]["text"], "workload_id": r.workload_id, "value": round(v, 3), "unit": "Msamples/s", "steps": steps_, "warmup": warm_,
+            out[mode] = {"traversal": MODES[mode]["text"] + (", binary tree (PLOC) and collapse built on the device" if mode == "wide" else ""), "workload_id": r.workload_id, "value": round(v, 3), "unit": "Msamples/s", "steps": steps_, "warmup": warm_,
                          "ms_per_step": round(r.elapsed / steps_ * 1e3, 3), "vs_parity": round(v / parity_value, 3) if parity_value else None,
                          "rt_create_s": round(r.t_create, 2), "build_ms": {k: round(v, 2) for k, v in r.build_times.items()}, "roofline": rf}
             r.close()
@@ -527,7 +529,7 @@ def main() -> None:
                 "ranks_formed": run.ranks_formed,
                 "film": "device (rt_render_rgb8)" if film else "none (linear float3)",
                 "traversal": MODES[args.mode]["text"],
-                "bvh": "reference topology, host build" if args.bvh == "reference" else "LBVH built on the device (identical closest hits, different topology and counters)",
+                "bvh": "reference topology, host build" if args.bvh == "reference" else "built on the device (PLOC; identical closest hits, different topology and counters)",
             },
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

@@ -12,6 +12,8 @@ struct DeviceBvh {
     WideNode *wide = nullptr; // the 8-wide tree, collapsed on the device (tris / attrs are then in ITS order)
     uint32_t n_wide = 0, wide_depth = 0;
     double wide_ms = 0;
+    bool ploc = false;        // the binary tree came from PLOC (else: Karras radix tree)
+    uint32_t rounds = 0;      // PLOC rounds
     DevTri *tris = nullptr;
     DevAttr *attrs = nullptr;
     uint32_t n_inner = 0, n_tris = 0, root = RT_NONE;

@@ -260,6 +260,80 @@ __device__ __forceinline__ float box_area6(const float *b) { // surface area of 
     return (dx >= 0.0f && dy >= 0.0f && dz >= 0.0f) ? 2.0f * (dx * dy + dy * dz + dz * dx) : 0.0f;
 }
 
+// The wide collapse's dynamic program for one binary node (wide_build.cpp step 2; children are complete by construction):
+// C(n, i) = cheapest representation of the subtree as at most i roots, i = 1..7, and the decisions that reach it.
+__device__ __forceinline__ void dp_node(const BuildArrays &A, uint32_t node, uint32_t lref, uint32_t rref, const float *l6, const float *r6, const float *box) {
+    const float INF = __builtin_inff();
+    float cl[7], cr[7];
+    uint32_t nl = 1u, nr = 1u;
+    if (lref & RT_LEAF_FLAG) {
+        const float a = box_area6(l6) * A.cost_tri;
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            cl[i] = a;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            cl[i] = __hip_atomic_load(A.dp_cost + 7ull * lref + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nl = __hip_atomic_load(A.dp_ntris + lref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (rref & RT_LEAF_FLAG) {
+        const float a = box_area6(r6) * A.cost_tri;
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            cr[i] = a;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            cr[i] = __hip_atomic_load(A.dp_cost + 7ull * rref + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nr = __hip_atomic_load(A.dp_ntris + rref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float area = box_area6(box);
+    const uint32_t nt = nl + nr;
+    unsigned long long dec = 0ull;
+    float dist[9];
+#pragma unroll
+    for (int j = 2; j <= 8; ++j) {
+        float best = INF;
+        int bk = 1;
+#pragma unroll
+        for (int k = 1; k < j; ++k) {
+            if (k > 7 || j - k > 7)
+                continue;
+            const float c = cl[k - 1] + cr[j - k - 1];
+            if (c < best) {
+                best = c;
+                bk = k;
+            }
+        }
+        dist[j] = best;
+        dec |= (unsigned long long)bk << (3 * (j - 2));
+    }
+    const float c_leaf = nt <= RT_WIDE_MAX_LEAF_TRIS ? area * (float)nt * A.cost_tri : INF;
+    const float c_internal = dist[8] + area * A.cost_node;
+    if (c_leaf <= c_internal)
+        dec |= 1ull << 42;
+    float c[7];
+    int eff = 1;
+    c[0] = fminf(c_leaf, c_internal);
+    dec |= 1ull << 21;
+#pragma unroll
+    for (int i = 2; i <= 7; ++i) {
+        if (dist[i] < c[i - 2]) {
+            c[i - 1] = dist[i];
+            eff = i;
+        } else {
+            c[i - 1] = c[i - 2];
+        }
+        dec |= (unsigned long long)eff << (21 + 3 * (i - 1));
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+        A.dp_cost[7ull * node + i] = c[i];
+    A.dp_ntris[node] = nt;
+    A.dp_dec[node] = dec;
+}
+
 // ---- 5. refit: the second arrival at a node owns it. Hand-off between workgroups: the first arrival has stored its
 // subtree's box, fenced (agent-scope release) and bumped the counter; the second one sees counter == 1, fences
 // (agent-scope acquire) and reads that box (MI355X_MICROARCH.md, inter-workgroup visibility).
@@ -303,82 +377,146 @@ __global__ __launch_bounds__(256) void k_refit(const BuildArrays A) {
                 box[c] = fminf(l6[c], r6[c]);
                 box[3 + c] = fmaxf(l6[3 + c], r6[3 + c]);
             }
-            if (A.dp_cost) { // the wide collapse's dynamic program for this node (wide_build.cpp step 2), children first by construction
-                const float INF = __builtin_inff();
-                float cl[7], cr[7];
-                uint32_t nl = 1u, nr = 1u;
-                if (lref & RT_LEAF_FLAG) {
-                    const float a = box_area6(l6) * A.cost_tri;
-#pragma unroll
-                    for (int i = 0; i < 7; ++i)
-                        cl[i] = a;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 7; ++i)
-                        cl[i] = __hip_atomic_load(A.dp_cost + 7ull * lref + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    nl = __hip_atomic_load(A.dp_ntris + lref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (rref & RT_LEAF_FLAG) {
-                    const float a = box_area6(r6) * A.cost_tri;
-#pragma unroll
-                    for (int i = 0; i < 7; ++i)
-                        cr[i] = a;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 7; ++i)
-                        cr[i] = __hip_atomic_load(A.dp_cost + 7ull * rref + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    nr = __hip_atomic_load(A.dp_ntris + rref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                const float area = box_area6(box);
-                const uint32_t nt = nl + nr;
-                unsigned long long dec = 0ull;
-                float dist[9];
-#pragma unroll
-                for (int j = 2; j <= 8; ++j) {
-                    float best = INF;
-                    int bk = 1;
-#pragma unroll
-                    for (int k = 1; k < j; ++k) {
-                        if (k > 7 || j - k > 7)
-                            continue;
-                        const float c = cl[k - 1] + cr[j - k - 1];
-                        if (c < best) {
-                            best = c;
-                            bk = k;
-                        }
-                    }
-                    dist[j] = best;
-                    dec |= (unsigned long long)bk << (3 * (j - 2));
-                }
-                const float c_leaf = nt <= RT_WIDE_MAX_LEAF_TRIS ? area * (float)nt * A.cost_tri : INF;
-                const float c_internal = dist[8] + area * A.cost_node;
-                if (c_leaf <= c_internal)
-                    dec |= 1ull << 42;
-                float c[7];
-                int eff = 1;
-                c[0] = fminf(c_leaf, c_internal);
-                dec |= 1ull << 21;
-#pragma unroll
-                for (int i = 2; i <= 7; ++i) {
-                    if (dist[i] < c[i - 2]) {
-                        c[i - 1] = dist[i];
-                        eff = i;
-                    } else {
-                        c[i - 1] = c[i - 2];
-                    }
-                    dec |= (unsigned long long)eff << (21 + 3 * (i - 1));
-                }
-#pragma unroll
-                for (int i = 0; i < 7; ++i)
-                    A.dp_cost[7ull * node + i] = c[i];
-                A.dp_ntris[node] = nt;
-                A.dp_dec[node] = dec;
-            }
+            if (A.dp_cost)
+                dp_node(A, node, lref, rref, l6, r6, box);
             child_is_leaf = 0u;
             child = node;
             node = A.node_parent[node];
         }
     }
+}
+
+// ---- 4b / 5b. PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) instead of the radix tree + refit: the
+// Morton-ordered leaves are clusters; every round each cluster looks RADIUS positions to either side for the neighbour whose
+// union box with it has the smallest surface area, mutual nearest neighbours merge into an inner node, the survivors are
+// compacted (order kept), until one cluster is left. Agglomerative with a real surface-area criterion: the tree it builds is
+// close to a full SAH build where the plain LBVH only ever splits at Morton-code bits. Boxes are unions of exact boxes, so
+// every stored child box is still the exact bounding box of its subtree.
+struct Ploc {
+    uint32_t *ref[2];   // cluster -> leaf ref / inner node index, double buffered
+    float *box[2];      // [6] per cluster
+    uint32_t *nn;       // nearest neighbour (cluster position)
+    uint32_t *valid;    // 1 = survives this round (also holds the merged cluster), 0 = absorbed
+    uint32_t *pos;      // exclusive scan of valid
+    uint32_t *depth;    // per inner node: height of its subtree (leaves 0)
+    uint32_t *counters; // [0] inner nodes allocated, [1] root height (written with the last merge)
+    uint32_t m;         // clusters this round
+    int cur;            // which buffer holds them
+    int radius;
+    int force;          // no mutual pair last round (cannot happen with consistent tie-breaking): pair neighbours 2k, 2k + 1
+};
+#define PLOC_MAX_RADIUS 32
+__global__ __launch_bounds__(256) void k_ploc_nn(const Ploc P) {
+    __shared__ float s_box[256 + 2 * PLOC_MAX_RADIUS][6];
+    const int m = (int)P.m, R = P.radius;
+    const int block0 = (int)(blockIdx.x * blockDim.x);
+    const float *box = P.box[P.cur];
+    for (int t = (int)threadIdx.x; t < 256 + 2 * R; t += 256) {
+        const int g = block0 - R + t;
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            s_box[t][c] = (g >= 0 && g < m) ? box[6ull * g + c] : 0.0f;
+    }
+    __syncthreads();
+    const int i = block0 + (int)threadIdx.x;
+    if (i >= m)
+        return;
+    if (P.force) {
+        P.nn[i] = (uint32_t)((i ^ 1) < m ? (i ^ 1) : i);
+        return;
+    }
+    const float *bi = s_box[threadIdx.x + R];
+    float best = __builtin_inff();
+    int bj = i;
+    for (int dj = -R; dj <= R; ++dj) {
+        const int j = i + dj;
+        if (dj == 0 || j < 0 || j >= m)
+            continue;
+        const float *bjx = s_box[threadIdx.x + R + dj];
+        float u[6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            u[c] = fminf(bi[c], bjx[c]);
+            u[3 + c] = fmaxf(bi[3 + c], bjx[3 + c]);
+        }
+        const float a = box_area6(u);
+        if (a < best) { // ascending j: on equal areas the lower position wins, on both sides of a pair
+            best = a;
+            bj = j;
+        }
+    }
+    P.nn[i] = (uint32_t)bj;
+}
+__global__ __launch_bounds__(256) void k_ploc_merge(const Ploc P, const BuildArrays A) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.m)
+        return;
+    const uint32_t j = P.nn[i];
+    const bool mutual = j != i && P.nn[j] == i;
+    if (!mutual) {
+        P.valid[i] = 1u;
+        return;
+    }
+    if (i > j) {
+        P.valid[i] = 0u; // absorbed into position j
+        return;
+    }
+    const uint32_t lref = P.ref[P.cur][i], rref = P.ref[P.cur][j];
+    float l6[6], r6[6], u[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        l6[c] = P.box[P.cur][6ull * i + c];
+        r6[c] = P.box[P.cur][6ull * j + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        u[c] = fminf(l6[c], r6[c]);
+        u[3 + c] = fmaxf(l6[3 + c], r6[3 + c]);
+    }
+    const uint32_t node = atomicAdd(P.counters + 0, 1u);
+    DevNode &nd = A.nodes[node];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        nd.lmin[c] = l6[c];
+        nd.lmax[c] = l6[3 + c];
+        nd.rmin[c] = r6[c];
+        nd.rmax[c] = r6[3 + c];
+    }
+    nd.left = lref;
+    nd.right = rref;
+    nd.pad[0] = nd.pad[1] = 0;
+    const uint32_t dl = (lref & RT_LEAF_FLAG) ? 0u : P.depth[lref], dr = (rref & RT_LEAF_FLAG) ? 0u : P.depth[rref];
+    const uint32_t d = 1u + (dl > dr ? dl : dr);
+    P.depth[node] = d;
+    if (A.dp_cost)
+        dp_node(A, node, lref, rref, l6, r6, u);
+    // the merged cluster takes position i
+    P.ref[P.cur][i] = node;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+        P.box[P.cur][6ull * i + c] = u[c];
+    P.valid[i] = 1u;
+    if (P.m == 2u)
+        P.counters[1] = d; // the last merge: height of the whole tree
+}
+__global__ __launch_bounds__(256) void k_ploc_compact(const Ploc P) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.m || !P.valid[i])
+        return;
+    const uint32_t q = P.pos[i];
+    P.ref[P.cur ^ 1][q] = P.ref[P.cur][i];
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+        P.box[P.cur ^ 1][6ull * q + c] = P.box[P.cur][6ull * i + c];
+}
+__global__ __launch_bounds__(256) void k_ploc_init(const Ploc P, const BuildArrays A) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n_leaves)
+        return;
+    P.ref[0][i] = leaf_ref(A, i);
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+        P.box[0][6ull * i + c] = A.leaf_box[6ull * i + c];
 }
 
 // ---- 6. wide collapse, top down (RT_BUILD_WIDE on the device tree): one thread per wide node of the current level.
@@ -748,10 +886,74 @@ hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBv
     BUILD_TRY(hipMemsetAsync(leaf_parent, 0xFF, 4ull * n_leaves, stream)); // RT_NONE: a single leaf has no parent
     const int lblocks = (int)std::min<uint64_t>(((uint64_t)n_leaves + 255) / 256, 256u * 16u);
     BUILD_TRY(RT_LAUNCH_CHECKED(k_leaves, dim3(lblocks), dim3(256), 0, stream, A));
-    if (n_leaves > 1) {
+    // binary tree over the leaves: PLOC (default) or the Karras radix tree + refit (RT_DEVICE_BUILDER=lbvh; also the fallback when
+    // a PLOC tree comes out deeper than the traversal stacks allow)
+    uint32_t bin_root = 0u;
+    const char *builder_env = std::getenv("RT_DEVICE_BUILDER");
+    bool use_ploc = n_leaves > 1 && !(builder_env && !std::strcmp(builder_env, "lbvh"));
+    if (use_ploc) {
+        Ploc P{};
+        // search radius: 8 positions to either side measured best on both bench scenes (S-sponza / S-10M, wide tree collapsed from
+        // it: radius 2: 452 / 217 Msamples/s, 4: 495 / 224, 6: 502 / 224, 8: 496 / 244, 16: 464 / 228, 32: 465 / 231; profiles/r03_wide.txt)
+        int radius = 8;
+        if (const char *e = std::getenv("RT_PLOC_RADIUS"))
+            radius = std::min(PLOC_MAX_RADIUS, std::max(1, std::atoi(e)));
+        P.radius = radius;
+        for (int k = 0; k < 2; ++k) {
+            BUILD_TRY(tmp.alloc(&P.ref[k], (size_t)n_leaves));
+            BUILD_TRY(tmp.alloc(&P.box[k], 6ull * n_leaves));
+        }
+        BUILD_TRY(tmp.alloc(&P.nn, (size_t)n_leaves));
+        BUILD_TRY(tmp.alloc(&P.valid, (size_t)n_leaves));
+        BUILD_TRY(tmp.alloc(&P.pos, (size_t)n_leaves));
+        BUILD_TRY(tmp.alloc(&P.depth, (size_t)n_leaves));
+        BUILD_TRY(tmp.alloc(&P.counters, (size_t)4));
+        BUILD_TRY(hipMemsetAsync(P.counters, 0, 4 * sizeof(uint32_t), stream));
+        size_t scan_bytes = 0;
+        BUILD_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, P.valid, P.pos, 0u, (size_t)n_leaves, rocprim::plus<uint32_t>(), stream));
+        char *scan_tmp;
+        BUILD_TRY(tmp.alloc(&scan_tmp, scan_bytes));
+        BUILD_TRY(RT_LAUNCH_CHECKED(k_ploc_init, dim3((n_leaves + 255u) / 256u), dim3(256), 0, stream, P, A)); // one thread per leaf (not grid-stride)
+        P.m = n_leaves;
+        P.cur = 0;
+        int rounds = 0;
+        while (P.m > 1) {
+            const dim3 grid((P.m + 255u) / 256u);
+            BUILD_TRY(RT_LAUNCH_CHECKED(k_ploc_nn, grid, dim3(256), 0, stream, P));
+            BUILD_TRY(RT_LAUNCH_CHECKED(k_ploc_merge, grid, dim3(256), 0, stream, P, A));
+            size_t sb = scan_bytes;
+            BUILD_TRY(rocprim::exclusive_scan(scan_tmp, sb, P.valid, P.pos, 0u, (size_t)P.m, rocprim::plus<uint32_t>(), stream));
+            BUILD_TRY(RT_LAUNCH_CHECKED(k_ploc_compact, grid, dim3(256), 0, stream, P));
+            uint32_t last[2];
+            BUILD_TRY(hipMemcpyAsync(&last[0], P.pos + (P.m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            BUILD_TRY(hipMemcpyAsync(&last[1], P.valid + (P.m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            BUILD_TRY(hipStreamSynchronize(stream));
+            const uint32_t m_new = last[0] + last[1];
+            P.force = m_new == P.m ? 1 : 0; // no progress: pair neighbours next round
+            P.m = m_new;
+            P.cur ^= 1;
+            if (++rounds > 4096) {
+                if (err)
+                    *err = "PLOC did not terminate";
+                return hipErrorUnknown;
+            }
+        }
+        uint32_t h_root, h_counters[4];
+        BUILD_TRY(hipMemcpyAsync(&h_root, P.ref[P.cur], sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        BUILD_TRY(hipMemcpyAsync(h_counters, P.counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
+        BUILD_TRY(hipStreamSynchronize(stream));
+        bin_root = h_root;
+        out->rounds = (uint32_t)rounds;
+        if (h_counters[0] != n_leaves - 1u || h_counters[1] > 60u) // deeper than the traversal stacks (RT_MAX_STACK 64): take the depth-bounded radix tree
+            use_ploc = false;
+    }
+    if (n_leaves > 1 && !use_ploc) {
+        BUILD_TRY(hipMemsetAsync(arrived, 0, 4ull * n_leaves, stream));
         BUILD_TRY(RT_LAUNCH_CHECKED(k_radix_tree, dim3(lblocks), dim3(256), 0, stream, A));
         BUILD_TRY(RT_LAUNCH_CHECKED(k_refit, dim3(lblocks), dim3(256), 0, stream, A));
+        bin_root = 0u;
     }
+    out->ploc = use_ploc;
     uint32_t h_bounds[8];
     BUILD_TRY(hipMemcpyAsync(h_bounds, bounds, sizeof(h_bounds), hipMemcpyDeviceToHost, stream));
     BUILD_TRY(hipStreamSynchronize(stream));
@@ -772,7 +974,7 @@ hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBv
         BUILD_TRY(tmp.alloc(&queue[1], (size_t)n_leaves));
         BUILD_TRY(tmp.alloc(&counters, (size_t)4));
         const uint32_t init_counters[4] = {1u, 0u, 0u, 0u}; // record 0 = the root
-        const uint2 root_entry = make_uint2(0u, 0u);         // binary inner node 0 (Karras: the root) -> wide record 0
+        const uint2 root_entry = make_uint2(bin_root, 0u);   // the binary root (Karras: node 0; PLOC: the last merge) -> wide record 0
         BUILD_TRY(hipMemcpyAsync(counters, init_counters, sizeof(init_counters), hipMemcpyHostToDevice, stream));
         BUILD_TRY(hipMemcpyAsync(queue[0], &root_entry, sizeof(root_entry), hipMemcpyHostToDevice, stream));
         BUILD_TRY(hipStreamSynchronize(stream));
@@ -819,7 +1021,7 @@ hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBv
     out->attrs = A.attrs;
     out->n_inner = n_leaves > 1 ? n_leaves - 1 : 0;
     out->n_tris = n;
-    out->root = n_leaves > 1 ? 0u : (RT_LEAF_FLAG | (n << 27) | 0u);
+    out->root = n_leaves > 1 ? bin_root : (RT_LEAF_FLAG | (n << 27) | 0u);
     out->fast_ok = h_bounds[6] == 0u;
     for (int c = 0; c < 3; ++c) {
         out->lo[c] = dec_f(h_bounds[c]);

@@ -45,7 +45,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # one GPU: the production modes ride on the same line, each with its own record, and are faster than parity or say so
     pr = j["production"]
     for mode in ("global", "wide"):
-        assert pr[mode]["value"] > 0 and pr[mode]["roofline"]["pipeline"]["nodes_per_cast"] > 0 and pr[mode]["workload_id"].startswith("sponza-custom-")
+        assert pr[mode]["value"] > 0 and pr[mode]["roofline"]["pipeline"]["nodes_per_cast"] > 0 and pr[mode]["workload_id"].startswith("sponza-custom")
     assert j["extra_workloads"] is None  # custom sizes: no S-10M leg
     assert j["config"]["launcher"] == "single" and j["config"]["ranks_formed"] == 1
     cb = j["cpu_baseline"]
@@ -65,7 +65,7 @@ def test_committed_profiles_are_stamped_and_stale_ones_are_never_quoted():
 
     sha = bench.kernel_source_hash()
     strict = os.environ.get("RT_STRICT_PROFILES") == "1"
-    for wl in ("sponza", "s10m", "sponza-wide", "s10m-wide"):
+    for wl in ("sponza", "s10m", "sponza-dev-wide", "s10m-dev-wide"):
         for name in ("hbm_traffic", "pmc_wf_extend"):
             path = os.path.join(ROOT, "profiles", f"{bench.PROFILE_ROUND}_{name}_{wl}.json")
             if not os.path.exists(path):  # not profiled (yet) this round: the bench line then carries null + "absent", nothing stale

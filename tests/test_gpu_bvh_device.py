@@ -121,8 +121,13 @@ def _compare_hits_with_oracle(orc, dev, rays, max_tie_share):
     return share
 
 
-@pytest.mark.parametrize("case", ["room_5000", "boxes", "tiny_1", "tiny_2", "tiny_5", "tiny_9", "room_1M"])
-def test_device_lbvh_invariants_and_closest_hits(gpu, oracle, sg, case):
+@pytest.mark.parametrize("case", ["room_5000", "boxes", "tiny_1", "tiny_2", "tiny_5", "tiny_9", "room_1M", "room_5000/lbvh", "boxes/lbvh", "tiny_9/lbvh", "room_1M/lbvh"])
+def test_device_lbvh_invariants_and_closest_hits(gpu, oracle, sg, case, monkeypatch):
+    """Both binary builders of rt_bvh_device.hip: PLOC (default; agglomerative clustering along the Morton order) and the Karras
+    radix tree + refit (RT_DEVICE_BUILDER=lbvh, also PLOC's fallback for trees deeper than the traversal stacks)."""
+    case, _, builder = case.partition("/")
+    if builder:
+        monkeypatch.setenv("RT_DEVICE_BUILDER", builder)
     if case.startswith("room"):
         n = 5000 if case == "room_5000" else 1_000_000
         sc = sg.room_scene(n, seed=3, n_lights=6, n_materials=8, tex_size=8, n_tex_sets=2, offset=0.15 if n == 5000 else 0.05)
@@ -159,7 +164,7 @@ def test_device_lbvh_invariants_and_closest_hits(gpu, oracle, sg, case):
         differing = float((rel > 1e-5).any(axis=2).mean())
         assert differing <= (0.02 if case == "boxes" else 0.002), differing  # only paths through an exact tie can differ
         t_dev = dev.build_times()
-        print(f"\\n[{case}] triangles {sc.n_triangles}: device LBVH build {t_dev['build_ms']:.2f} ms (+ upload {t_dev['upload_ms']:.1f} ms), depth {depth}, "
+        print(f"\\n[{case}] {builder or 'ploc'}: triangles {sc.n_triangles}: device build {t_dev['build_ms']:.2f} ms (+ upload {t_dev['upload_ms']:.1f} ms), depth {depth}, "
               f"tie share vs oracle {ties:.2e}, pixels beyond 1e-5 of the oracle {differing:.2e}")
     finally:
         orc.close()

@@ -3,7 +3,7 @@
 set -e
 tag=${1:?tag}; rnd=${2:-r03}
 cd "$(dirname "$0")/.."
-for id in sponza sponza-wide s10m s10m-wide; do
+for id in sponza sponza-dev-wide s10m s10m-dev-wide; do
   for f in hbm_traffic pmc_wf_extend pmc_wf_shade pmc_wf_extend_packet bench; do
     [ -f gpurun_out/${tag}_${f}_${id}.json ] && cp gpurun_out/${tag}_${f}_${id}.json profiles/${rnd}_${f}_${id}.json
   done

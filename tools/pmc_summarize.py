@@ -19,13 +19,14 @@ import bench  # noqa: E402  (kernel_source_hash, WORKLOADS)
 
 wl_name, tag, pmc_spp = sys.argv[1], sys.argv[2], int(sys.argv[3])
 mode = sys.argv[4] if len(sys.argv) > 4 else "parity"
-wl = wl_name + bench.MODES[mode]["suffix"]  # = bench.py's workload_id: names the output files
+bvh = sys.argv[5] if len(sys.argv) > 5 else "reference"
+wl = wl_name + ("-dev" if bvh == "device" else "") + bench.MODES[mode]["suffix"]  # = bench.py's workload_id: names the output files
 O = os.path.join(ROOT, "gpurun_out")
 W = bench.WORKLOADS[wl_name]
 # the closest-hit kernels of this mode (every one of their launches is what bench.py times as "the dominant kernel")
-EXTEND = ("wf_extend_wide<false",) if mode == "wide" else ("wf_extend<false", "wf_extend_packet<false")
+EXTEND = ("wf_extend_wide<false", "wf_extend_wide_packet<false") if mode == "wide" else ("wf_extend<false", "wf_extend_packet<false")
 sha = bench.kernel_source_hash()
-workload = f"{W['label']} {W['width']}x{W['height']} n={W['triangles']} mode={mode}"
+workload = f"{W['label']} {W['width']}x{W['height']} n={W['triangles']} mode={mode} bvh={bvh}"
 
 
 def collect(dirglob, kernel):
@@ -63,7 +64,7 @@ if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
         "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
         "avg_launch_ms_under_pmc": dur["FETCH_SIZE"] / n["FETCH_SIZE"],
         "correction": "gfx950: FETCH_SIZE reports 64 B per 128-B read request -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; x1024 (KB)",
-        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over python3 bench.py (one warm-up render first: the packet policy has settled) --workload {wl_name} --mode {mode} --no-extras --no-cpu-baseline --steps 1 --warmup 1, averaged over the closest-hit dispatches",
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over python3 bench.py (one warm-up render first: the packet policy has settled) --workload {wl_name} --mode {mode} --bvh {bvh} --no-extras --no-cpu-baseline --steps 1 --warmup 1, averaged over the closest-hit dispatches",
     }
     json.dump(out, open(os.path.join(O, f"{tag}_hbm_traffic_{wl}.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
@@ -71,7 +72,7 @@ else:
     print("no FETCH_SIZE/WRITE_SIZE data", dict(agg))
 
 # ---- SQ / TCP / TCC counters
-for kern, short in ((("wf_extend_wide<false",) if mode == "wide" else ("wf_extend<false",), "wf_extend"), (("wf_extend_packet<false",), "wf_extend_packet"), (("wf_shade<false",), "wf_shade")):
+for kern, short in ((("wf_extend_wide<false",) if mode == "wide" else ("wf_extend<false",), "wf_extend"), (("wf_extend_wide_packet<false",) if mode == "wide" else ("wf_extend_packet<false",), "wf_extend_packet"), (("wf_shade<false",), "wf_shade")):
     agg, dur, n = collect(f"{tag}_pmc_sq*_{wl}", kern)
     if not agg:
         print("no SQ data for", kern)

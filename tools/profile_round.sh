@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# tools/profile_round.sh <workload: sponza|s10m> [tag] [mode: parity|wide|global] — round deliverables for one bench workload and
+# tools/profile_round.sh <workload: sponza|s10m> [tag] [mode: parity|wide|global] [bvh: reference|device] — round deliverables for one bench workload and
 # traversal mode, on the GPU box:
 #   1. the bench.py run of that workload / mode                         -> gpurun_out/<tag>_bench_<id>.json
 #   2. rocprofv3 --kernel-trace --stats of the same command             -> gpurun_out/<tag>_stats_<id>/
@@ -8,11 +8,11 @@
 # <id> = bench.py's workload_id (sponza, sponza-wide, s10m, ...). Every summary is stamped with the hash of the device sources
 # (bench.py kernel_source_hash) so a later bench run can tell whether it still describes the kernels it is running. Copy what
 # should be judged from gpurun_out/ into profiles/ (tools/install_profiles.sh).
-wl=${1:-sponza}; tag=${2:-r03}; mode=${3:-parity}
+wl=${1:-sponza}; tag=${2:-r03}; mode=${3:-parity}; bvh=${4:-reference}
 export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; mkdir -p $O
-id=$wl; [ "$mode" = wide ] && id=$wl-wide; [ "$mode" = global ] && id=$wl-gbest
+id=$wl; [ "$bvh" = device ] && id=$wl-dev; [ "$mode" = wide ] && id=$id-wide; [ "$mode" = global ] && id=$id-gbest
 if [ "$wl" = s10m ]; then pmc_spp=8; else pmc_spp=16; fi
-extra="--workload $wl --mode $mode --no-extras"
+extra="--workload $wl --mode $mode --bvh $bvh --no-extras"
 cpu=""; { [ "$wl" = s10m ] || [ "$mode" != parity ]; } && cpu="--no-cpu-baseline"  # the CPU leg is on the default bench line (S-sponza, parity)
 python3 $R/bench.py $extra $cpu > $O/${tag}_bench_$id.json 2> $O/${tag}_bench_$id.err; echo "bench exit $?"; tail -c 1500 $O/${tag}_bench_$id.json
 cd /tmp
@@ -30,4 +30,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d $O/${tag}_pmc_sq${i}_$id --pmc $set -- python3 $R/bench.py $extra --no-cpu-baseline --steps 1 --warmup 0 --spp $pmc_spp > $O/${tag}_pmc_sq${i}_$id.log 2>&1 || echo "sq pass $i failed"
 done
 cd $R
-python3 tools/pmc_summarize.py $wl $tag $pmc_spp $mode
+python3 tools/pmc_summarize.py $wl $tag $pmc_spp $mode $bvh
