@@ -77,11 +77,11 @@ WORKLOADS = {
     "s10m": dict(label="S-10M", width=2048, height=2048, spp_per_gpu=32, triangles=10_000_000, offset=0.03, tex_size=1024, cpu_share=256,
                  metric="Msamples/sec (whole node) on synthetic 10M-triangle scene 2048x2048"),
 }
-# everything that decides what the closest-hit kernels do and how they are launched: kernels, layouts, the tree builders, the
-# launch geometry and workspace policy in rt_scene.cpp, and the compiler flags
-DEVICE_SOURCES = tuple("raytracing-course-hw-public_amd/csrc/" + f for f in (
-    "rt_wavefront.hip", "rt_wide.hip", "rt_device_lib.h", "rt_device_types.h", "rt_kernels.h", "rt_scene.cpp", "bvh_build.cpp", "wide_build.cpp",
-    "rt_bvh_device.hip", "Makefile")) + ("include/rt_devspec.h",)
+# everything that decides what the closest-hit kernels do and how they are launched (kernels, layouts, the tree builders, the
+# launch geometry and workspace policy in rt_scene.cpp, the compiler flags): ONE list, csrc/device_sources.txt, hashed here and by
+# the Makefile, which builds the hash into librt_amd.so (rt_source_stamp)
+CSRC = os.path.join(ROOT, "raytracing-course-hw-public_amd", "csrc")
+DEVICE_SOURCES = tuple(ln.strip() for ln in open(os.path.join(CSRC, "device_sources.txt")) if ln.strip() and not ln.startswith("#"))
 MODES = {
     "parity": dict(suffix="", wide=False, gbest=False, text="reference tree, reference order and pruning (parity mode)"),
     "global": dict(suffix="-gbest", wide=False, gbest=True, text="reference tree, global-best pruning (production)"),
@@ -93,7 +93,7 @@ def kernel_source_hash() -> str:
     """sha256 over the device-side sources: stamps PMC profiles so that a stale one is never quoted."""
     h = hashlib.sha256()
     for rel in DEVICE_SOURCES:
-        with open(os.path.join(ROOT, rel), "rb") as f:
+        with open(os.path.join(CSRC, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
@@ -407,6 +407,10 @@ def main() -> None:
     import torch  # imported BEFORE the HIP library so that one HIP runtime serves both (same soname)
 
     rt = importlib.import_module("raytracing-course-hw-public_amd")
+    lib_stamp = rt.lib().rt_source_stamp().decode()
+    if lib_stamp != kernel_source_hash() and not os.environ.get("RT_AMD_LIB"):  # (tuning variants are measured under their own name)
+        raise SystemExit(f"librt_amd.so was built from other sources (stamp {lib_stamp}) than this tree ({kernel_source_hash()}): "
+                         "run ./build.sh first; a bench line must describe the sources it is committed with")
     in_process = int(os.environ.get("WORLD_SIZE", "1")) <= 1 and args.gpus > 1
     launcher, rank, local_rank, world = resolve_launch(args.gpus, visible_devices=torch.cuda.device_count() if in_process else None)
     dist = None

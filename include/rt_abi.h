@@ -289,6 +289,9 @@ int rt_film_rgb8(rt_scene *scene, const float *rgb, size_t n_pixels, uint8_t *ou
 
 const char *rt_last_error(void);
 uint32_t rt_abi_version(void);
+/* First 16 hex digits of the sha256 over the device-side sources this library was built from (csrc/device_sources.txt): lets a
+ * caller (bench.py, __graft_entry__.build) check that the binary it measures is the tree it describes. */
+const char *rt_source_stamp(void);
 int rt_device_count(void);
 
 #ifdef __cplusplus

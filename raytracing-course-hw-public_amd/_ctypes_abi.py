@@ -155,6 +155,7 @@ ABI_PROTOTYPES = {
     "rt_render_rgb8": (C.c_int, [C.c_void_p, C.POINTER(RtParams), C.c_void_p, C.POINTER(RtStats)]),
     "rt_film_rgb8": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_u8_p]),
     "rt_last_error": (C.c_char_p, []),
+    "rt_source_stamp": (C.c_char_p, []),
     "rt_abi_version": (C.c_uint32, []),
     "rt_device_count": (C.c_int, []),
     "rt_create_on": (C.c_int, [C.POINTER(RtSceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),

@@ -324,3 +324,70 @@ def test_wide_on_the_bench_scene(gpu, oracle, sg):
                   f"(oracle, binary: {ost['nodes_visited'] / ost['casts']:.1f} / {ost['tri_tests'] / ost['casts']:.1f})")
         finally:
             dev.close()
+
+
+# ------------------------------------------------------------------------------------------------ edge cases of the production build
+def _tiny_scene(sg, n_tris, seed):
+    """n_tris triangles in front of a camera at the origin looking down -z; the last one is emissive."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform([-2.0, -1.5, -7.0], [2.0, 1.5, -4.0], size=(n_tris, 1, 3))
+    pos = (c + rng.uniform(-2.0, 2.0, size=(n_tris, 3, 3)) * np.array([1.0, 1.0, 0.3])).astype(np.float32)
+    mats = [sg.Material(color=(0.7, 0.6, 0.5, 1.0), roughness=0.6, metallic=0.2), sg.Material(color=(1, 1, 1, 1), emission=(1.0, 0.9, 0.8), emissive_strength=9.0, roughness=1.0, metallic=0.0)]
+    ids = np.zeros(n_tris, dtype=np.uint32)
+    ids[-1] = 1
+    tang = np.tile(np.array([1, 0, 0], dtype=np.float32), (n_tris, 3, 1))
+    return sg.Scene(positions=pos, normals=None, texcoords=rng.uniform(0, 1, size=(n_tris, 3, 2)).astype(np.float32), tangents=tang, material_ids=ids,
+                    materials=mats, textures=[], camera=sg.look_camera((0.0, 0.0, 0.0), yaw_deg=0.0, yfov=0.9, aspect=32 / 24))
+
+
+@pytest.mark.parametrize("n_tris", [0, 1, 2, 3, 4, 8, 9, 10, 17, 40])
+def test_wide_on_tiny_scenes(gpu, oracle, sg, n_tris):
+    """A root that is a single leaf slot, fewer children than slots, the switch between the host collapse (<= 8 triangles) and the
+    device collapse (> 8), the empty scene: hits and renders against the oracle for both ways to build the wide tree."""
+    sc = _tiny_scene(sg, n_tris, seed=100 + n_tris) if n_tris else sg.room_scene(0, seed=1, n_lights=0, open_room=True)
+    orc = oracle.OracleScene(sc)
+    rng = np.random.default_rng(n_tris)
+    d = rng.normal(size=(4000, 3)).astype(np.float32) * np.array([1.0, 1.0, 0.4], dtype=np.float32) + np.array([0, 0, -1.0], dtype=np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([rng.normal(scale=0.5, size=(4000, 3)).astype(np.float32), d.astype(np.float32)], axis=1)
+    op, ob = orc.cast_rays(rays)
+    ofb, _ = orc.run_raytracer(32, 24, 4, seed=3)
+    try:
+        for kw in (dict(wide=True), dict(wide=True, device_bvh=True)):
+            dev = gpu.DeviceScene(sc, **kw)
+            try:
+                for mode in (gpu.RT_CAST_EXTEND, gpu.RT_CAST_PACKET):
+                    gp, gb, _ = dev.cast_rays_ex(rays, mode)
+                    ties, closer = compare_superset_hits_with_oracle(op, ob, gp, gb, f"{n_tris} triangles {kw} mode {mode}")
+                    assert ties + closer == 0, (n_tris, kw, mode, ties, closer)
+                if n_tris:
+                    dump = dev.bvh_wide_dump()
+                    from test_wide_build import walk_and_check
+
+                    walk_and_check(dump["nodes"], dump["tris"][:, 9].copy(), sc.positions)
+                gfb, _ = dev.run_raytracer(32, 24, 4, seed=3)
+                rel = np.abs(gfb - ofb) / np.maximum(np.abs(ofb), 1e-6)
+                assert rel.max() <= 1e-5, (n_tris, kw, float(rel.max()))
+            finally:
+                dev.close()
+    finally:
+        orc.close()
+
+
+def test_wide_with_analytic_primitives(gpu, oracle, tmp_path):
+    """Scene-txt scenes (BASELINE configs 1-2) through the production build: BOX / TRIANGLE primitives in the wide tree, ELLIPSOID /
+    PLANE through wf_extend_prims after it; the oracle's image within 1e-5."""
+    import os
+
+    txt = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "txt", "cornell_mixed.txt")
+    ls = gpu.parse_scene_txt(txt)
+    orc = oracle.OracleScene(ls)
+    ofb, ost = orc.run_raytracer(48, 40, 6, seed=4)
+    orc.close()
+    for kw in (dict(wide=True), dict(wide=True, device_bvh=True)):
+        dev = gpu.DeviceScene(ls, **kw)
+        gfb, gst = dev.run_raytracer(48, 40, 6, seed=4, counters=True)
+        dev.close()
+        rel = np.abs(gfb - ofb) / np.maximum(np.abs(ofb), 1e-6)
+        assert (rel > 1e-5).any(axis=2).mean() <= 0.01, (kw, float(rel.max()))
+        assert abs(gst["casts"] - ost["casts"]) <= 0.002 * ost["casts"]
