@@ -112,3 +112,19 @@ def test_bench_never_reports_more_gpus_than_took_part(tmp_path):
         assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 2
     else:
         assert "GPU(s) visible" in r.stderr and not r.stdout.strip()
+
+
+def test_library_carries_the_hash_of_its_sources(rt):
+    """librt_amd.so is stamped at build time with the sha256 of csrc/device_sources.txt's files (rt_source_stamp); bench.py hashes the
+    same list at run time and refuses to measure a library built from other sources. After a build the two must agree, and the
+    list must name the kernels, the layouts, the builders, the launch policy and the Makefile (a launch-geometry change
+    in rt_scene.cpp or a flag in the Makefile used to keep quoting stale counters)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert rt.lib().rt_source_stamp().decode() == bench.kernel_source_hash()
+    names = {os.path.basename(f) for f in bench.DEVICE_SOURCES}
+    for must in ("rt_wavefront.hip", "rt_wide.hip", "rt_device_lib.h", "rt_device_types.h", "rt_kernels.h", "rt_scene.cpp", "wide_build.cpp", "rt_bvh_device.hip", "Makefile", "rt_devspec.h"):
+        assert must in names, must
+    for f in bench.DEVICE_SOURCES:
+        assert os.path.exists(os.path.join(bench.CSRC, f)), f
