@@ -916,6 +916,67 @@ DEV C4 tex_sample(const DevScene &S, int32_t tex, int dflt, float u, float v, bo
     return (1 - dx) * ((1 - dy) * p00 + dy * p01) + dx * ((1 - dy) * p10 + dy * p11);
 }
 
+// The same four lookups when all of a material's textures are members of ONE interleaved view set (DevMaterial::tex_set): equal
+// size and tiling, record = {colour, emissive, metallic-roughness, normal} texel at one position. Texture::sample's address
+// arithmetic (wrap, truncation, neighbours: geometry.h:545-563) is the same for every member, so it is done once, and each of the
+// four neighbouring records is ONE 16-byte load instead of a 4-byte load per member; every member is then decoded and blended
+// with exactly tex_sample's operations in tex_sample's order, so each result is bit-identical to the slot-by-slot path.
+struct TexSet {
+    C4 color, emissive, mr, normal;
+};
+template <bool STATS>
+DEV TexSet tex_sample_set(const DevScene &S, int32_t view, uint32_t info, float u, float v, const float *s_lin, const float *s_gam, LaneStats<STATS> &st) {
+    DevTexture T;
+    {
+        const uint4 *tp = reinterpret_cast<const uint4 *>(S.textures + view);
+        const uint4 t0 = tp[0], t1 = tp[1];
+        T.width = t0.x, T.height = t0.y, T.offset = t0.z, T.count = t0.w;
+        T.stride = t1.x, T.tiles_x = t1.y, T.tw_log = t1.z, T.th_log = t1.w;
+    }
+    const uint32_t base = T.offset - ((info >> 4) & 3u); // dword 0 of record (0, 0)
+    float tx = wrap_repeat(u) * (float)T.width;
+    float ty = wrap_repeat(v) * (float)T.height;
+    int px = (int)tx;
+    int py = (int)ty;
+    float dx = tx - (float)px;
+    float dy = ty - (float)py;
+    const int w = (int)T.width, h = (int)T.height;
+    int x0 = px, x1 = mod_inc(px, w), y0 = py, y1 = mod_inc(py, h);
+    auto at = [&](int x, int y) {
+        const uint32_t tile = ((uint32_t)y >> T.th_log) * T.tiles_x + ((uint32_t)x >> T.tw_log);
+        const uint32_t within = (((uint32_t)y & ((1u << T.th_log) - 1u)) << T.tw_log) | ((uint32_t)x & ((1u << T.tw_log) - 1u));
+        return *reinterpret_cast<const uint4 *>(S.texels + base + ((tile << (T.tw_log + T.th_log)) + within) * 4u);
+    };
+    uint4 q00, q01, q10, q11;
+    if (px < w && py < h) {
+        q00 = at(x0, y0), q01 = at(x0, y1), q10 = at(x1, y0), q11 = at(x1, y1);
+    } else { // wrap_repeat rounded up to 1.0f: see tex_sample
+        auto flat = [&](int x, int y) {
+            const int over = x >= 2 * w ? 2 : (x >= w ? 1 : 0);
+            int row = y + over, col = x - over * w;
+            if (row >= h) {
+                row = h - 1;
+                col = w - 1;
+            }
+            return at(col, row);
+        };
+        q00 = flat(x0, y0), q01 = flat(x0, y1), q10 = flat(x1, y0), q11 = flat(x1, y1);
+    }
+    auto blend = [&](uint32_t a00, uint32_t a01, uint32_t a10, uint32_t a11, bool gamma) {
+        st.texels(4);
+        const float *rgb = gamma ? s_gam : s_lin;
+        auto dec = [&](uint32_t p) { return C4{rgb[p & 255u], rgb[(p >> 8) & 255u], rgb[(p >> 16) & 255u], s_lin[p >> 24]}; };
+        C4 p00 = dec(a00), p01 = dec(a01), p10 = dec(a10), p11 = dec(a11);
+        return (1 - dx) * ((1 - dy) * p00 + dy * p01) + dx * ((1 - dy) * p10 + dy * p11);
+    };
+    TexSet r;
+    r.normal = (info & 8u) ? blend(q00.w, q01.w, q10.w, q11.w, false) : C4{0.5f, 0.5f, 1, 0}; // NORMAL_UP geometry.h:602
+    r.mr = (info & 4u) ? blend(q00.z, q01.z, q10.z, q11.z, false) : C4{1, 1, 1, 1};             // WHITE_TEXTURE geometry.h:601
+    r.color = (info & 1u) ? blend(q00.x, q01.x, q10.x, q11.x, true) : C4{1, 1, 1, 1};
+    r.emissive = (info & 2u) ? blend(q00.y, q01.y, q10.y, q11.y, true) : C4{1, 1, 1, 1};
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------- shading record
 struct Surf { // ray_intersection_info bvh.h:18-29
     V3 normal, shading_normal;
@@ -980,12 +1041,21 @@ DEV Surf make_surf(const DevScene &S, const Hit &h, V3 ro, V3 rd, const float *s
     float tv = at.uv[1] * w0 + at.uv[3] * b + at.uv[5] * c;
     V3 tangent = norm(ld3(at.tg) * w0 + ld3(at.tg + 3) * b + ld3(at.tg + 6) * c);
     V3 bitangent = crs(smooth, tangent);
-    C4 nt = tex_sample(S, m.normal_tex, TEX_DEFAULT_NORMAL_UP, tu, tv, false, s_lin, s_gam, st); // sample_normal geometry.h:577-582
-    V3 normal_loc = norm(mk(nt.r, nt.g, nt.b) * 2 - 1);
-    V3 shading = norm(transform3(normal_loc, tangent, bitangent, smooth));
-    C4 mr = tex_sample(S, m.mr_tex, TEX_DEFAULT_WHITE, tu, tv, false, s_lin, s_gam, st); // geometry.h:623-626
-    C4 ct = tex_sample(S, m.color_tex, TEX_DEFAULT_WHITE, tu, tv, true, s_lin, s_gam, st); // :615-617
-    C4 et = tex_sample(S, m.emissive_tex, TEX_DEFAULT_WHITE, tu, tv, true, s_lin, s_gam, st); // :619-621
+    C4 nt, mr, ct, et;
+    V3 shading;
+    if (m.tex_set >= 0) { // all lookups of this material in one interleaved set: addresses once, one 16-byte load per neighbour
+        const TexSet ts = tex_sample_set(S, m.tex_set, m.tex_set_info, tu, tv, s_lin, s_gam, st);
+        nt = ts.normal, mr = ts.mr, ct = ts.color, et = ts.emissive;
+        V3 normal_loc = norm(mk(nt.r, nt.g, nt.b) * 2 - 1);
+        shading = norm(transform3(normal_loc, tangent, bitangent, smooth));
+    } else {
+        nt = tex_sample(S, m.normal_tex, TEX_DEFAULT_NORMAL_UP, tu, tv, false, s_lin, s_gam, st); // sample_normal geometry.h:577-582
+        V3 normal_loc = norm(mk(nt.r, nt.g, nt.b) * 2 - 1);
+        shading = norm(transform3(normal_loc, tangent, bitangent, smooth));
+        mr = tex_sample(S, m.mr_tex, TEX_DEFAULT_WHITE, tu, tv, false, s_lin, s_gam, st); // geometry.h:623-626
+        ct = tex_sample(S, m.color_tex, TEX_DEFAULT_WHITE, tu, tv, true, s_lin, s_gam, st); // :615-617
+        et = tex_sample(S, m.emissive_tex, TEX_DEFAULT_WHITE, tu, tv, true, s_lin, s_gam, st); // :619-621
+    }
     st.shaded();
     SD_STAMP(SD_TEX);
     {

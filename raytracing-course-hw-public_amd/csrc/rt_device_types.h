@@ -67,7 +67,9 @@ struct alignas(16) DevMaterial {
     float metallic;
     float ior;
     int32_t color_tex, emissive_tex, mr_tex, normal_tex; // -1 = WHITE_TEXTURE / NORMAL_UP
-    uint32_t pad[2];
+    int32_t tex_set;       // >= 0: EVERY texture this material samples is a member of ONE interleaved view set (rt_scene.cpp): the view of
+                           //       one of its members (tex_sample_set: addresses once, a 16-byte load per record). -1: sample slot by slot
+    uint32_t tex_set_info; // bits 0..3: slots present (1 colour, 2 emissive, 4 metallic-roughness, 8 normal); bits 4..5: record dword of view `tex_set`
 };
 static_assert(sizeof(DevMaterial) == 64, "DevMaterial must be 64 bytes");
 
