@@ -65,7 +65,8 @@ enum {
  *   RT_RNG_REFERENCE : the reference's stream: std::minstd_rand seeded with the 256-pixel span index
  *                   (raytracer.h:458,648; config.h:13) and the libstdc++-11 distribution algorithms,
  *                   one sequential stream per span. On the GPU one lane walks one span (parity mode,
- *                   not a performance mode). sin/cos still use the shared polynomial on the device.
+ *                   not a performance mode). sin/cos are glibc's sinf / cosf restated bit for bit
+ *                   (rt_devspec.h rt_sincos_libm): the image is the reference binary's, byte for byte.
  */
 enum { RT_RNG_DEVICE = 0, RT_RNG_REFERENCE = 1 };
 

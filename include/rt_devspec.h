@@ -10,9 +10,10 @@
  *                    (bits/random.tcc generate_canonical; bits/uniform_int_dist.h:277-330, the two-division
  *                    "fallback" downscaling branch), used in RT_RNG_REFERENCE mode.
  *   3. rt_sincos   : sin/cos of an angle in [0, 2*pi] evaluated in double precision (Cody-Waite quadrant
- *                    reduction + Taylor/minimax polynomials) and rounded once to float. The reference calls glibc
- *                    cosf/sinf (raytracer.h:104,158-159); glibc's results are not reproducible on a GPU, so
- *                    device parity is defined against this function ("Hop 2").
+ *                    reduction + Taylor/minimax polynomials) and rounded once to float: RT_RNG_DEVICE mode's
+ *                    definition of sin/cos ("Hop 2").
+ *   4. rt_sincos_libm : glibc's sinf / cosf restated bit for bit, which is what the reference's std::sin / std::cos
+ *                    (raytracer.h:104,158-159) evaluate: RT_RNG_REFERENCE mode on the device.
  *
  * Only +,-,*,/ on float/double and integer ops are used; with floating-point contraction disabled
  * (-ffp-contract=off, both compilers) the results are bit-identical on x86-64 and gfx950.
@@ -161,6 +162,62 @@ RT_HD void rt_sincos(float phi, float *s_out, float *c_out) {
     }
     *s_out = (float)s;
     *c_out = (float)c;
+}
+
+/* ---------------------------------------------------------------- sin / cos, the reference's own ---- */
+/* The reference calls std::sin / std::cos on floats (raytracer.h:104,158-159): glibc's sinf / cosf. In RT_RNG_REFERENCE mode the
+ * device evaluates THAT function: glibc 2.35 sysdeps/ieee754/flt-32/{s_sinf.c, s_cosf.c, sincosf.h} (the ARM Optimized Routines
+ * algorithm: double-precision arithmetic, reduction by multiples of pi/2 with a 2^24-scaled 2/pi, two polynomials), restated with
+ * its constants (they are also what the installed libm.so.6 holds in __sincosf_table). Only the branch structure for
+ * 0 <= y < 120 is restated; the render loop's arguments are azimuths in [0, 2*pi]. tools/proofs/sincosf_exhaustive.c compares this
+ * function with the host libm on EVERY float in [0, 2*pi] (1 086 918 636 values, both with and without contraction of the
+ * multiply-adds: the final rounding to float absorbs the difference) — run by the CPU suite. With it the GPU's reference-RNG
+ * render is the reference binary's image byte for byte, not merely the oracle's. */
+RT_HD float rt_libm_poly(double x, double x2, double cs, int n) { /* sinf_poly; cs = +1: table entry 0, -1: entry 1 (cosine coefficients negated) */
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double s1 = S2 + x2 * S3;
+        const double x7 = x3 * x2;
+        const double s = x + x3 * S1;
+        return (float)(s + x7 * s1);
+    }
+    const double x4 = x2 * x2;
+    const double c2 = cs * C3 + x2 * (cs * C4);
+    const double c1 = cs * C0 + x2 * (cs * C1);
+    const double x6 = x4 * x2;
+    const double c = c1 + x4 * (cs * C2);
+    return (float)(c + x6 * c2);
+}
+RT_HD void rt_sincos_libm(float y, float *s_out, float *c_out) {
+    const double HPI_INV = 0x1.45f306dc9c883p+23, HPI = 0x1.921fb54442d18p+0; /* 2^24 * 2/pi, pi/2 */
+    union {
+        float f;
+        uint32_t u;
+    } b;
+    b.f = y;
+    const uint32_t top12 = (b.u >> 20) & 0x7ffu; /* abstop12 */
+    double x = (double)y;
+    if (top12 < 0x3f4u) {      /* abstop12(y) < abstop12(pio4): |y| < 0.75 */
+        if (top12 < 0x398u) {  /* |y| < 2^-12 */
+            *s_out = y;
+            *c_out = 1.0f;
+            return;
+        }
+        const double x2 = x * x;
+        *s_out = rt_libm_poly(x, x2, 1.0, 0);
+        *c_out = rt_libm_poly(x, x2, 1.0, 1);
+        return;
+    }
+    /* reduce_fast: n = round(x * 2/pi) through the 2^24-scaled product, x -= n * pi/2 */
+    const double r = x * HPI_INV;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - (double)n * HPI;
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0; /* sign[n & 3] = {1, -1, -1, 1} */
+    const double cs = (n & 2) ? -1.0 : 1.0;
+    *s_out = rt_libm_poly(x * sgn, x * x, cs, n);
+    *c_out = rt_libm_poly(x * sgn, x * x, cs, n ^ 1);
 }
 
 #endif /* RT_DEVSPEC_H */

@@ -173,13 +173,14 @@ def test_queue_shapes_match_oracle(pairs, gpu, shape):
 
 @pytest.mark.parametrize("name", ["room_plain", "room_textured", "room_manylights"])
 def test_render_reference_rng_matches_oracle(pairs, gpu, name):
-    """RT_RNG_REFERENCE: the reference's minstd stream per 256-pixel span, one lane per span. With the shared sincos
-    on both sides the framebuffers must agree to 1e-5 (observed: bit-identical) -> identical PPM bytes."""
+    """RT_RNG_REFERENCE: the reference's minstd stream per 256-pixel span, one lane per span, and the reference's
+    std::sin / std::cos: the oracle calls the host's glibc (as the reference binary does), the device evaluates the
+    restatement of glibc's sinf / cosf (include/rt_devspec.h rt_sincos_libm). Bit-identical framebuffers."""
     dev, orc, _ = pairs[name]
     W, H, SPP = 48, 40, 3
     gfb, _ = dev.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_REFERENCE)
-    ofb, _ = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_REFERENCE, libm_sincos=False)
-    assert _rel_err(gfb, ofb).max() <= REL_TOL
+    ofb, _ = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_REFERENCE, libm_sincos=True)
+    assert np.array_equal(gfb.view(np.uint32), ofb.view(np.uint32))
     assert np.array_equal(gpu.tonemap(gfb), gpu.tonemap(ofb))
 
 
@@ -486,16 +487,16 @@ def test_cli_end_to_end(gpu, oracle, sg, tmp_path):
     assert r.returncode == 1 and r.stderr.strip() != ""
 
 
-def test_reference_rng_mode_close_to_reference_binary_golden(gpu, sg, oracle, tmp_path):
-    """GPU in RT_RNG_REFERENCE mode against the golden PPM the unmodified reference produced. The only difference
-    left is sin/cos (shared polynomial on the device, glibc in the reference), i.e. rare last-bit differences of a
-    sampled direction: report how close the bytes are and require near-identity."""
+def test_reference_rng_mode_equals_reference_binary_golden(gpu, sg, oracle, tmp_path):
+    """GPU in RT_RNG_REFERENCE mode against the golden PPM the unmodified reference binary produced (tests/golden,
+    made by oracle/make_golden.py from /root/reference's own sources): the same random stream, the same sinf / cosf,
+    the same arithmetic -> the same bytes, without the oracle in between."""
     import os
 
     from conftest import golden_scene_specs, make_scene
 
     gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    for name in ("room_plain", "boxes"):
+    for name in ("room_plain", "room_textured", "room_manylights", "boxes", "open_nolight"):
         sc = make_scene(sg, golden_scene_specs()[name])
         path = sg.write_gltf(sc, str(tmp_path / (name + ".gltf")))
         ls = gpu.parse_gltf_scene(path, 64 / 48)
@@ -504,17 +505,15 @@ def test_reference_rng_mode_close_to_reference_binary_golden(gpu, sg, oracle, tm
         img = gpu.tonemap(fb)
         ref = oracle.read_ppm(os.path.join(gold_dir, f"{name}_64x48x4.ppm"))
         differing = int((img != ref).any(axis=2).sum())
-        # observed (tools/closeness_probe.py): room_plain 22 of 3072 pixels (0.7 %), boxes 0
-        assert differing <= 0.02 * 64 * 48, f"{name}: {differing} of {64 * 48} pixels differ from the reference binary's PPM"
+        assert differing == 0, f"{name}: {differing} of {64 * 48} pixels differ from the reference binary's PPM"
         dev.close()
 
 
 def test_feature_gltf_through_loader_matches_oracle_and_reference(gpu, oracle):
     """The hand-built loader-feature glTF (tests/golden/features: scene selection, matrix + TRS nodes, strips, u8/u16/u32
     indices, missing attributes, emissive texture + strength, mixed texture sizes) through the C++ loader onto the GPU:
-    bit-exact against the oracle in device-RNG mode, and in reference-RNG mode close to the PPM the unmodified reference
-    binary produced. (Only sin/cos last-bit differences remain; a flipped decision shifts the rest of that 256-pixel
-    span's sequential random stream, so whole spans re-sample: bounded share of pixels, small mean difference.)"""
+    bit-exact against the oracle in device-RNG mode, and in reference-RNG mode byte-identical to the PPM the unmodified
+    reference binary produced."""
     import os
 
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -528,9 +527,7 @@ def test_feature_gltf_through_loader_matches_oracle_and_reference(gpu, oracle):
     img, _ = dev.run_raytracer_rgb8(64, 48, 4, rng_mode=gpu.RT_RNG_REFERENCE)
     ref = oracle.read_ppm(os.path.join(gold, "features_64x48x4.ppm"))
     differing = int((img != ref).any(axis=2).sum())
-    mean_abs = float(np.abs(img.astype(np.int32) - ref.astype(np.int32)).mean())
-    # observed (tools/closeness_probe.py): 170 of 3072 pixels (5.5 %), mean |d| 2.23; bound = observed + ~50 % margin
-    assert differing <= 0.085 * 64 * 48 and mean_abs < 3.3, f"{differing} of {64 * 48} pixels differ from the reference binary's PPM, mean |d| {mean_abs}"
+    assert differing == 0, f"{differing} of {64 * 48} pixels differ from the reference binary's PPM"
     dev.close()
     orc.close()
 

@@ -88,8 +88,12 @@ def test_txt_scene_matches_oracle(gpu, oracle, name):
             dev.run_raytracer(W, H, SPP, seed=31, shard_index=r, shard_count=3, shard_block=256, out=sh)
         assert np.array_equal(sh.view(np.uint32), ofb.view(np.uint32))
         rfb, _ = dev.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE)
-        orf, _ = orc.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE, libm_sincos=False)
+        orf, _ = orc.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE, libm_sincos=True)
         assert np.array_equal(rfb.view(np.uint32), orf.view(np.uint32))
+        if name == "boxes_only":  # ... and the reference binary's own bytes for this scene (tests/test_scene_txt.py pins the fixture)
+            img, _ = dev.run_raytracer_rgb8(64, 48, 4, rng_mode=gpu.RT_RNG_REFERENCE)
+            gold = oracle.read_ppm(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "txt_boxes_64x48x4.ppm"))
+            assert np.array_equal(img, gold)
     finally:
         dev.close()
         orc.close()

@@ -150,6 +150,20 @@ def test_one_step_exact_division_hard_cases(tmp_path):
     assert ", failures 0 " in r.stdout and "random failures 0" in r.stdout
 
 
+def test_libm_sincos_restatement_is_exhaustively_glibc(tmp_path):
+    """rt_sincos_libm (include/rt_devspec.h), which the device evaluates in reference-RNG mode where the reference calls
+    std::sin / std::cos (raytracer.h:104,158-159), equals the host's glibc sinf / cosf on EVERY float in [0, 2*pi]
+    (1.09e9 values, tools/proofs/sincosf_exhaustive.c) — the last link of "GPU image = the reference binary's image"."""
+    import subprocess
+
+    exe = str(tmp_path / "sincosf_exhaustive")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "proofs", "sincosf_exhaustive.c"), "-o", exe, "-lm", "-lpthread"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches against libm sinf/cosf: 0 " in r.stdout
+
+
 # ------------------------------------------------------------------------------------------------ film / PPM / PNG
 def test_tonemap_matches_oracle_film(rt, oracle):
     rng = np.random.default_rng(3)
