@@ -20,8 +20,8 @@
  *                                                                      pow(c, 2.2f) of geometry.h:525-527 are done
  *                                                                      by bit-exact 256-entry tables)
  *   scene.camera                (scene.h:60-72)                     -> rt_camera
- *   scene.bg_color, scene.bg    (scene.h:75,81; main.cpp:28-31)     -> bg_color (bg texture is the 1x1 white default,
- *                                                                      USE_ENV_MAP=false, config.h:37)
+ *   scene.bg_color, scene.bg    (scene.h:75,81; main.cpp:28-31)     -> bg_color, bg_texture (RT_TEX_NONE = the 1x1 white default of
+ *                                                                      USE_ENV_MAP=false, config.h:37; else the environment map)
  *   scene.ray_depth, samples    (scene.h:76-77)                     -> rt_scene_desc.ray_depth, rt_params.samples
  * Reference output at the seam:
  *   image.set_pixel(p_idx, render_pixel(...)) (raytracer.h:658) which tone-maps at once (image.h:40-42,79-82)
@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2u /* 2: rt_scene_desc carries analytic primitives (scene-txt front end) */
+#define RT_ABI_VERSION 3u /* 2: rt_scene_desc carries analytic primitives (scene-txt front end); 3: bg_texture (environment map) */
 #define RT_TEX_NONE (-1)
 #define RT_ALL_DEVICES (-1) /* rt_create: one scene replica on every visible GPU + an RCCL communicator over them */
 
@@ -128,6 +128,9 @@ typedef struct rt_scene_desc {
     uint32_t n_primitives; /* analytic primitives, tested by brute force next to the BVH (at most RT_MAX_PRIMITIVES) */
     const rt_primitive_desc *primitives;
     uint32_t build_flags; /* RT_BUILD_* */
+    int32_t bg_texture;   /* Scene::bg (scene.h:81; main.cpp:29-31, config.h:36-38 USE_ENV_MAP / ENV_MAP_PATH): index into `textures` of the
+                             environment map that Scene::bg_at (scene.h:83-89) samples by direction, RT_TEX_NONE = the reference's default, the
+                             1x1 WHITE_TEXTURE (a constant bg_color background). Loaders: rt_loaded_scene_set_env_map (rt_host.h) */
 } rt_scene_desc;
 /* How rt_create builds the scene BVH (BVH::build, bvh.h:262-393):
  *   RT_BUILD_REFERENCE (default): on the host, in the reference's exact topology (same SAH sweep, same std::sort
@@ -253,6 +256,10 @@ int rt_cast_rays_ex(rt_scene *scene, const float *rays, uint32_t n, uint32_t mod
 
 /* Light-pdf probe: bvh_mix_dist::pdf (raytracer.h:363-375) for n (origin, dir) pairs. */
 int rt_light_pdf(rt_scene *scene, const float *rays, uint32_t n, float *pdf_out);
+
+/* Background probe: Scene::bg_at (scene.h:83-89) for n directions (3 floats each, as the render loop passes ray.dir: unit length is
+ * the caller's business) -> n x rgb. With bg_texture = RT_TEX_NONE every answer is bg_color. */
+int rt_bg_at(rt_scene *scene, const float *dirs, uint32_t n, float *rgb_out);
 
 /* BVH introspection for parity tests: which = 0 scene_bvh, 1 light_bvh. Nodes are reported in the
  * reference's own pre-order numbering (bvh.h:157-163, 351-363): 10 x u32-sized words per node

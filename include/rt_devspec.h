@@ -220,4 +220,148 @@ RT_HD void rt_sincos_libm(float y, float *s_out, float *c_out) {
     *c_out = rt_libm_poly(x * sgn, x * x, cs, n ^ 1);
 }
 
+/* ---------------------------------------------------------------- atan2 / asin, the reference's own ---- */
+/* Scene::bg_at (scene.h:83-89) maps a direction to environment-map coordinates with std::atan2 / std::asin on floats: glibc's atan2f /
+ * asinf, which on x86-64 are the single-precision fdlibm routines (sysdeps/ieee754/flt-32/{e_atan2f.c, s_atanf.c, e_asinf.c}: float
+ * arithmetic only, no FMA variant is selected at run time). Restated here with their constants and compared with the installed libm by
+ * tools/proofs/atan2f_asinf_exhaustive.c: atanf and asinf on ALL 2^32 floats, atan2f on 10^9 random pairs (uniform bit patterns and pairs
+ * of comparable magnitude) plus the special-case grid — 0 mismatches. The errno-setting wrappers do not change values. Used in BOTH RNG
+ * modes: the environment lookup is the reference's arithmetic, not a definition of ours. */
+RT_HD uint32_t rt_f2u(float f) {
+    union {
+        float f;
+        uint32_t u;
+    } b;
+    b.f = f;
+    return b.u;
+}
+RT_HD float rt_u2f(uint32_t u) {
+    union {
+        float f;
+        uint32_t u;
+    } b;
+    b.u = u;
+    return b.f;
+}
+RT_HD float rt_atanf_libm(float x) {
+    const float hi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f}; /* atan(0.5), atan(1), atan(1.5), atan(inf) */
+    const float lo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float a0 = 3.3333334327e-01f, a1 = -2.0000000298e-01f, a2 = 1.4285714924e-01f, a3 = -1.1111110449e-01f, a4 = 9.0908870101e-02f,
+                a5 = -7.6918758452e-02f, a6 = 6.6610731184e-02f, a7 = -5.8335702866e-02f, a8 = 4.9768779427e-02f, a9 = -3.6531571299e-02f,
+                a10 = 1.6285819933e-02f;
+    const int32_t hx = (int32_t)rt_f2u(x), ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) { /* |x| >= 2^25 */
+        if (ix > 0x7f800000)
+            return x + x;
+        return hx > 0 ? hi[3] + lo[3] : -hi[3] - lo[3];
+    }
+    if (ix < 0x3ee00000) { /* |x| < 0.4375 */
+        if (ix < 0x31000000)
+            return x; /* |x| < 2^-29 */
+        id = -1;
+    } else {
+        x = rt_u2f((uint32_t)ix);
+        if (ix < 0x3f980000) { /* |x| < 1.1875 */
+            if (ix < 0x3f300000) {
+                id = 0;
+                x = (2.0f * x - 1.0f) / (2.0f + x);
+            } else {
+                id = 1;
+                x = (x - 1.0f) / (x + 1.0f);
+            }
+        } else if (ix < 0x401c0000) { /* |x| < 2.4375 */
+            id = 2;
+            x = (x - 1.5f) / (1.0f + 1.5f * x);
+        } else {
+            id = 3;
+            x = -1.0f / x;
+        }
+    }
+    float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
+    const float s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
+    if (id < 0)
+        return x - x * (s1 + s2);
+    z = hi[id] - ((x * (s1 + s2) - lo[id]) - x);
+    return hx < 0 ? -z : z;
+}
+RT_HD float rt_atan2f_libm(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = (int32_t)rt_f2u(x), hy = (int32_t)rt_f2u(y), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000)
+        return x + y;
+    if (hx == 0x3f800000)
+        return rt_atanf_libm(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2); /* 2 * sign(x) + sign(y) */
+    if (iy == 0)
+        return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+    if (ix == 0)
+        return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000)
+            return m == 0 ? pi_o_4 + tiny : m == 1 ? -pi_o_4 - tiny : m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny;
+        return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7f800000)
+        return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int32_t k = (iy - ix) >> 23;
+    float z;
+    if (k > 60)
+        z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60)
+        z = 0.0f;
+    else
+        z = rt_atanf_libm(rt_u2f(rt_f2u(y / x) & 0x7fffffffu));
+    switch (m) {
+    case 0:
+        return z;
+    case 1:
+        return rt_u2f(rt_f2u(z) ^ 0x80000000u);
+    case 2:
+        return pi - (z - pi_lo);
+    default:
+        return (z - pi_lo) - pi;
+    }
+}
+RT_HD float rt_asinf_libm(float x) {
+    const float pio2_hi = 1.57079637050628662109375f, pio2_lo = -4.37113900018624283e-8f, pio4_hi = 0.785398185253143310546875f;
+    const float p0 = 1.666675248e-1f, p1 = 7.495297643e-2f, p2 = 4.547037598e-2f, p3 = 2.417951451e-2f, p4 = 4.216630880e-2f;
+    const int32_t hx = (int32_t)rt_f2u(x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000)
+        return x * pio2_hi + x * pio2_lo;
+    if (ix > 0x3f800000)
+        return (x - x) / (x - x); /* |x| > 1 or NaN: NaN */
+    if (ix < 0x3f000000) { /* |x| < 0.5 */
+        if (ix < 0x32000000)
+            return x;
+        const float t = x * x;
+        const float w = t * (p0 + t * (p1 + t * (p2 + t * (p3 + t * p4))));
+        return x + x * w;
+    }
+    float w = 1.0f - rt_u2f((uint32_t)ix);
+    float t = w * 0.5f;
+    float p = t * (p0 + t * (p1 + t * (p2 + t * (p3 + t * p4))));
+    const float s = __builtin_sqrtf(t);
+    if (ix >= 0x3F79999A) { /* |x| > 0.975 */
+        t = pio2_hi - (2.0f * (s + s * p) - pio2_lo);
+    } else {
+        w = rt_u2f(rt_f2u(s) & 0xfffff000u);
+        const float c = (t - w * w) / (s + w);
+        const float r = p;
+        p = 2.0f * s * r - (pio2_lo - 2.0f * c);
+        const float q = pio4_hi - 2.0f * w;
+        t = pio4_hi - (p - q);
+    }
+    return hx > 0 ? t : -t;
+}
+/* Scene::bg_at's coordinates (scene.h:85-87): x = 0.5 + 0.5 * atan2(z, x) / pi_f evaluated in double (the 0.5 literals are doubles, the
+ * float results are promoted) and rounded to float once; y = 0.5 - asin(y) / pi_f with the quotient in float and the difference in double. */
+RT_HD void rt_bg_uv(float dx, float dy, float dz, float *u, float *v) {
+    const float pi_f = 3.14159274101257324f; /* std::numbers::pi_v<float> */
+    *u = (float)(0.5 + 0.5 * (double)rt_atan2f_libm(dz, dx) / (double)pi_f);
+    *v = (float)(0.5 - (double)(rt_asinf_libm(dy) / pi_f));
+}
+
 #endif /* RT_DEVSPEC_H */

@@ -29,6 +29,10 @@ int rt_gltf_load(const char *path, float aspect, rt_loaded_scene **out);
 int rt_txt_load(const char *path, rt_loaded_scene **out);
 int rt_scene_load(const char *path, float aspect, rt_loaded_scene **out);
 int rt_loaded_info(const rt_loaded_scene *s, uint32_t *width, uint32_t *height, uint32_t *samples, uint32_t *ignored_lights);
+/* main.cpp:28-31 with USE_ENV_MAP = true (config.h:36-38): scene.bg = Texture::load_img(path) and bg_color = intensity. Decodes the
+ * picture (PNG / JPEG / Radiance HDR, as rt_image_decode_file), appends it to the scene's textures and points desc.bg_texture at it.
+ * The reference fixes path and intensity at compile time ("env.hdr", 1); the CLI takes them from RT_ENV_MAP / RT_ENV_MAP_INTENSITY. */
+int rt_loaded_set_env_map(rt_loaded_scene *s, const char *image_path, float intensity);
 const rt_scene_desc *rt_loaded_desc(const rt_loaded_scene *s);
 void rt_loaded_free(rt_loaded_scene *s);
 
@@ -58,8 +62,11 @@ int rt_bvh_wide_build_host(const float *positions, uint32_t n_triangles, float c
  * their signatures: PNG (every colour type / bit depth / Adam7 / tRNS) and JPEG (baseline, extended-sequential and progressive
  * Huffman, 8 bit, 1 or 3 components, any sampling factors that divide the maximum, restart intervals). Both return the bytes
  * stb_image v2.30 returns (pinned by fixtures decoded with the reference's own stb build). Other formats stb_image reads
- * (BMP, TGA, GIF, PSD, HDR, PNM) are refused with RT_ERR_FORMAT and a message that names the format. Caller frees with rt_free. */
+ * (BMP, TGA, GIF, PSD, PNM) are refused with RT_ERR_FORMAT and a message that names the format. Radiance HDR pictures (the
+ * reference's default environment map is "env.hdr") come back as stb_image's 8-bit conversion of them (gamma 2.2, scale 1), which is what
+ * the reference's stbi_load call receives. Caller frees with rt_free. */
 int rt_image_decode_file(const char *path, uint32_t *w, uint32_t *h, uint8_t **rgba8);
+int rt_hdr_decode_file(const char *path, uint32_t *w, uint32_t *h, uint8_t **rgba8);
 int rt_png_decode_file(const char *path, uint32_t *w, uint32_t *h, uint8_t **rgba8);
 int rt_jpeg_decode_file(const char *path, uint32_t *w, uint32_t *h, uint8_t **rgba8);
 void rt_free(void *p);

@@ -33,6 +33,7 @@ _PROTOS = {
     "rto_render": (C.c_int, [C.c_void_p, C.POINTER(_abi.RtParams), _abi.c_float_p, C.POINTER(_abi.RtStats), C.c_int, C.c_int]),
     "rto_cast_rays": (C.c_int, [C.c_void_p, _abi.c_float_p, C.c_uint32, _abi.c_u32_p, _abi.c_float_p]),
     "rto_light_pdf": (C.c_int, [C.c_void_p, _abi.c_float_p, C.c_uint32, _abi.c_float_p]),
+    "rto_bg_at": (C.c_int, [C.c_void_p, _abi.c_float_p, C.c_uint32, _abi.c_float_p]),
     "rto_bvh_info": (C.c_int, [C.c_void_p, C.c_int, _abi.c_u32_p, _abi.c_u32_p, _abi.c_u32_p, _abi.c_u32_p, _abi.c_u32_p]),
     "rto_tonemap_rgb8": (None, [_abi.c_float_p, C.c_size_t, _abi.c_u8_p]),
     "rto_last_error": (C.c_char_p, []),
@@ -113,6 +114,13 @@ class OracleScene:
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
         out = np.zeros(rays.shape[0], dtype=np.float32)
         _check(lib().rto_light_pdf(self._h, _abi.fptr(rays), rays.shape[0], _abi.fptr(out)))
+        return out
+
+    def bg_at(self, dirs):
+        """Scene::bg_at (scene.h:83-89) for explicit directions -> (n, 3) rgb."""
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((dirs.shape[0], 3), dtype=np.float32)
+        _check(lib().rto_bg_at(self._h, _abi.fptr(dirs), dirs.shape[0], _abi.fptr(out)))
         return out
 
     def bvh_info(self, which):

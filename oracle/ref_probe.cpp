@@ -8,6 +8,9 @@
 //   ref_probe primary  <gltf> <W> <H> <out.bin>            closest hits of pixel-centre rays gen_ray(camera,x,y)
 //   ref_probe lightpdf <gltf> <W> <H> <rays.bin> <out.bin> bvh_mix_dist::pdf for explicit (x, dir) pairs
 //   ref_probe scene    <gltf> <W> <H> <out.bin>            flattened scene.objects (positions/normals/uv/tangents)
+//   ref_probe bgat     <gltf> <W> <H> <image> <dirs.bin> <out.bin>  Scene::bg_at (scene.h:83-89) with scene.bg = load_img(image) as main.cpp:29-31
+//                                                          does under USE_ENV_MAP, for explicit directions (3 floats each) -> rgb
+//   ref_probe envrender <gltf> <W> <H> <image> <spp> <out.ppm>  main.cpp:27-43 with the environment map loaded: the reference's own render
 //   ref_probe texture  <image> 0 0 <out.bin>               geometry::Texture::load_img (the reference's stb_image build, 4 channels
 //                                                          forced, geometry.h:584-598): [width, height, texel floats r g b a ...]
 //
@@ -69,6 +72,31 @@ int main(int argc, char **argv) {
     scene.camera.width = width;
     scene.camera.height = height;
     scene.samples = 1;
+    if (mode == "bgat" || mode == "envrender") {
+        if (argc < 8) {
+            std::fprintf(stderr, "usage: ref_probe %s <gltf> <W> <H> <image> ...\n", mode.c_str());
+            return 2;
+        }
+        scene.bg = geometry::Texture::load_img(argv[5]); // main.cpp:29-31, the branch USE_ENV_MAP = false compiles out
+        if (mode == "envrender") {
+            scene.samples = std::strtol(argv[6], nullptr, 10);
+            Image img(width, height, scene.bg_color); // main.cpp:35-43
+            run_raytracer(scene, img);
+            std::ofstream out(argv[7], std::ios::binary);
+            img.write(out);
+            return 0;
+        }
+        std::vector<uint32_t> o;
+        auto f = read_floats(argv[6]);
+        for (size_t i = 0; i + 2 < f.size(); i += 3) {
+            geometry::color3 c = scene.bg_at({f[i], f[i + 1], f[i + 2]});
+            put_f32(o, c.r());
+            put_f32(o, c.g());
+            put_f32(o, c.b());
+        }
+        write_words(argv[7], o);
+        return 0;
+    }
     RaytracerStaticContext ctx(scene);
     const geometry::Object *base = scene.objects.data();
     std::vector<uint32_t> out;

@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <numbers>
 #include <string>
 #include <cstdlib>
 #include <thread>
@@ -466,6 +467,7 @@ struct rto_scene {
     Texture normal_up{1, 1, {{0.5f, 0.5f, 1, 0}}}; // NORMAL_UP geometry.h:602
     rt_camera cam;
     V3 bg_color;
+    const Texture *bg = nullptr; // Scene::bg scene.h:81 (WHITE_TEXTURE unless an environment map is given, main.cpp:29-31)
     unsigned ray_depth;
     BVH scene_bvh, light_bvh;
     // analytic primitives of the scene-txt front end (no reference implementation at HEAD: semantics defined by
@@ -753,14 +755,22 @@ template <class R> struct Integrator {
         V3 clr = trace_ray({pos, dir}, max_depth) * scl;
         return ii.emission + clr;
     }
-    // raytracer.h:593-605 ; Scene::bg_at scene.h:83-89 with the 1x1 white bg (main.cpp:28-31)
+    // Scene::bg_at scene.h:83-89. std::atan2 / std::asin on floats are glibc's atan2f / asinf, called here as the reference calls them;
+    // 0.5 and the products with it are doubles, the quotient asin / pi is a float. Texture::sample returns a 1x1 texture's texel at once.
+    V3 bg_at(V3 dir) {
+        float x = 0.5 + 0.5 * std::atan2(dir.z, dir.x) / std::numbers::pi_v<float>;
+        float y = 0.5 - std::asin(dir.y) / std::numbers::pi_v<float>;
+        C4 e = sc.bg->sample({x, y}, 2.2f, c.texels);
+        return sc.bg_color * V3{e.r, e.g, e.b};
+    }
+    // raytracer.h:593-605
     V3 trace_ray(const Ray &ray, unsigned max_depth) {
         if (max_depth == 0)
             return {0, 0, 0};
         IntersectionInfo ii;
         if (cast_ray(ray, ii))
             return shade(ray, ii, max_depth - 1);
-        return sc.bg_color * V3{1, 1, 1};
+        return bg_at(ray.dir);
     }
     // raytracer.h:527-538
     Ray gen_ray(int x, int y) {
@@ -905,6 +915,12 @@ int rto_create(const rt_scene_desc *d, rto_scene **out) {
         }
     s->cam = d->camera;
     s->bg_color = {d->bg_color[0], d->bg_color[1], d->bg_color[2]};
+    if (d->bg_texture >= (int32_t)d->n_textures) {
+        delete s;
+        g_err = "rto_create: bg_texture out of range";
+        return RT_ERR_INVALID_ARG;
+    }
+    s->bg = tex(d->bg_texture, &s->white);
     s->ray_depth = d->ray_depth;
     // RaytracerStaticContext raytracer.h:440-447
     s->scene_bvh = BVH::build(s->objects, [](const Object &) { return true; });
@@ -990,6 +1006,15 @@ int rto_light_pdf(rto_scene *s, const float *rays, uint32_t n, float *pdf_out) {
     for (uint32_t i = 0; i < n; ++i) {
         V3 x{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, d{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
         pdf_out[i] = it.has_lights() ? it.lights_pdf(x, d) : 0.0f;
+    }
+    return RT_OK;
+}
+
+int rto_bg_at(rto_scene *s, const float *dirs, uint32_t n, float *rgb_out) {
+    Integrator<RngXoshiro> it(*s, 1, 1, 1, false);
+    for (uint32_t i = 0; i < n; ++i) {
+        V3 c = it.bg_at({dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]});
+        rgb_out[3 * i] = c.x, rgb_out[3 * i + 1] = c.y, rgb_out[3 * i + 2] = c.z;
     }
     return RT_OK;
 }

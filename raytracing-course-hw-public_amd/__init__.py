@@ -96,6 +96,10 @@ class LoadedScene:
         _check(lib().rt_loaded_info(self._h, C.byref(w), C.byref(h), C.byref(s), C.byref(l)))
         return {"width": w.value, "height": h.value, "samples": s.value, "ignored_lights": l.value}
 
+    def set_env_map(self, image_path: str, intensity: float = 1.0) -> None:
+        """main.cpp:28-31 under USE_ENV_MAP: scene.bg = Texture::load_img(image_path), bg_color = intensity (rt_loaded_set_env_map)."""
+        _check(lib().rt_loaded_set_env_map(self._h, os.fsencode(image_path), C.c_float(intensity)))
+
     def close(self) -> None:
         if self._h:
             lib().rt_loaded_free(self._h)
@@ -263,6 +267,14 @@ class DeviceScene:
         n = rays.shape[0]
         out = np.zeros(n, dtype=np.float32)
         _check(lib().rt_light_pdf(self._h, fptr(rays), n, fptr(out)))
+        return out
+
+    def bg_at(self, dirs: np.ndarray) -> np.ndarray:
+        """Scene::bg_at (scene.h:83-89) for explicit directions -> (n, 3) rgb (rt_bg_at)."""
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        n = dirs.shape[0]
+        out = np.zeros((n, 3), dtype=np.float32)
+        _check(lib().rt_bg_at(self._h, fptr(dirs), n, fptr(out)))
         return out
 
     def bvh_device_dump(self, which: int = 0):

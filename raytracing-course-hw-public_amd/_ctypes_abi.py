@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 RT_PRIM_ELLIPSOID = 1
 RT_PRIM_PLANE = 2
 RT_BUILD_REFERENCE = 0
@@ -99,6 +99,7 @@ class RtSceneDesc(C.Structure):
         ("n_primitives", C.c_uint32),
         ("primitives", C.POINTER(RtPrimitiveDesc)),
         ("build_flags", C.c_uint32),
+        ("bg_texture", C.c_int32),
     ]
 
 
@@ -149,6 +150,7 @@ ABI_PROTOTYPES = {
     "rt_cast_rays": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, c_u32_p, c_float_p]),
     "rt_cast_rays_ex": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, C.c_uint32, c_u32_p, c_float_p, C.POINTER(RtStats)]),
     "rt_light_pdf": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, c_float_p]),
+    "rt_bg_at": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, c_float_p]),
     "rt_bvh_wide_dump": (C.c_int, [C.c_void_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
     "rt_bvh_info": (C.c_int, [C.c_void_p, C.c_int, c_u32_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
     "rt_tonemap_rgb8": (None, [c_float_p, C.c_size_t, c_u8_p]),
@@ -170,6 +172,8 @@ HOST_PROTOTYPES = {
     "rt_scene_load": (C.c_int, [C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),
     "rt_loaded_info": (C.c_int, [C.c_void_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
     "rt_loaded_desc": (C.POINTER(RtSceneDesc), [C.c_void_p]),
+    "rt_loaded_set_env_map": (C.c_int, [C.c_void_p, C.c_char_p, C.c_float]),
+    "rt_hdr_decode_file": (C.c_int, [C.c_char_p, c_u32_p, c_u32_p, C.POINTER(c_u8_p)]),
     "rt_loaded_free": (None, [C.c_void_p]),
     "rt_write_ppm": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, c_u8_p]),
     "rt_png_decode_file": (C.c_int, [C.c_char_p, c_u32_p, c_u32_p, C.POINTER(c_u8_p)]),
@@ -271,6 +275,7 @@ class DescHolder:
         d.n_primitives = len(prims)
         d.primitives = self.primitives
         d.build_flags = int(getattr(scene, "build_flags", 0))
+        d.bg_texture = int(getattr(scene, "bg_texture", -1))  # Scene::bg: index into textures, -1 = the white default
         self.desc = d
 
 
@@ -300,6 +305,7 @@ def desc_to_arrays(desc: RtSceneDesc) -> dict:
         },
         "bg_color": np.array(list(desc.bg_color), dtype=np.float32),
         "ray_depth": int(desc.ray_depth),
+        "bg_texture": int(desc.bg_texture),
         "primitives": [
             {"kind": int(desc.primitives[i].kind), "material_id": int(desc.primitives[i].material_id), "param": np.array(list(desc.primitives[i].param), dtype=np.float32),
              "position": np.array(list(desc.primitives[i].position), dtype=np.float32), "rotation": np.array(list(desc.primitives[i].rotation), dtype=np.float32)}

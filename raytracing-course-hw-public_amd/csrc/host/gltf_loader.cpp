@@ -411,6 +411,7 @@ void load_impl(const std::filesystem::path &gltf_path, float ar, rt_loaded_scene
     d.textures = res.textures.data();
     d.camera = cam;
     d.bg_color[0] = d.bg_color[1] = d.bg_color[2] = 1.0f; // ENV_MAP_INTENSITY config.h:36, main.cpp:28
+    d.bg_texture = RT_TEX_NONE;                           // USE_ENV_MAP = false config.h:37 (rt_loaded_set_env_map changes it)
     d.ray_depth = 8;                                      // DEFAULT_RAY_DEPTH config.h:17, scene.h:186
 }
 
@@ -430,6 +431,27 @@ extern "C" int rt_gltf_load(const char *path, float aspect, rt_loaded_scene **ou
         return rt::fail(RT_ERR_IO, e.what());
     }
     *out = s;
+    return RT_OK;
+}
+
+// main.cpp:28-31 for USE_ENV_MAP = true: scene.bg_color = intensity, scene.bg = Texture::load_img(path)
+extern "C" int rt_loaded_set_env_map(rt_loaded_scene *s, const char *image_path, float intensity) {
+    if (!s || !image_path)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_loaded_set_env_map: null argument");
+    uint32_t w = 0, h = 0;
+    uint8_t *px = nullptr;
+    if (int rc = rt_image_decode_file(image_path, &w, &h, &px); rc != RT_OK)
+        return rc;
+    s->texels.push_back(px);
+    rt_texture_desc t{};
+    t.width = w;
+    t.height = h;
+    t.rgba8 = px;
+    s->textures.push_back(t);
+    s->desc.textures = s->textures.data(); // the vector may have moved
+    s->desc.n_textures = (uint32_t)s->textures.size();
+    s->desc.bg_texture = (int32_t)s->textures.size() - 1;
+    s->desc.bg_color[0] = s->desc.bg_color[1] = s->desc.bg_color[2] = intensity;
     return RT_OK;
 }
 

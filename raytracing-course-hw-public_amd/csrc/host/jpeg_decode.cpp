@@ -763,7 +763,8 @@ extern "C" int rt_jpeg_decode_file(const char *path, uint32_t *w_out, uint32_t *
     return RT_OK;
 }
 
-// Texture::load_img (geometry.h:584-598) for the formats this loader reads: PNG and JPEG, told apart by their signatures.
+// Texture::load_img (geometry.h:584-598) for the formats this loader reads: PNG, JPEG and Radiance HDR (the environment map's default
+// format, hdr_decode.cpp), told apart by their signatures.
 extern "C" int rt_image_decode_file(const char *path, uint32_t *w_out, uint32_t *h_out, uint8_t **rgba_out) {
     if (!path)
         return rt::fail(RT_ERR_INVALID_ARG, "rt_image_decode_file: null argument");
@@ -777,5 +778,7 @@ extern "C" int rt_image_decode_file(const char *path, uint32_t *w_out, uint32_t 
     }
     if (sig[0] == 0xFF && sig[1] == 0xD8 && sig[2] == 0xFF)
         return rt_jpeg_decode_file(path, w_out, h_out, rgba_out);
+    if (sig[0] == '#' && sig[1] == '?')
+        return rt_hdr_decode_file(path, w_out, h_out, rgba_out);
     return rt_png_decode_file(path, w_out, h_out, rgba_out);
 }

@@ -3,7 +3,8 @@
 // The only change of substance is line 37 of the reference: run_raytracer(scene, img) becomes
 // rt_create + rt_render_rgb8 through the C ABI (include/rt_abi.h): render and film (image.h) on the device.
 // Optional environment: RT_DEVICE (HIP ordinal; unset = every visible GPU: replicas + RCCL gather inside the library, the
-// node-scale counterpart of the thread pool of raytracer.h:636-665), RT_RNG_MODE (device|reference), RT_SEED.
+// node-scale counterpart of the thread pool of raytracer.h:636-665), RT_RNG_MODE (device|reference), RT_SEED,
+// RT_ENV_MAP (+ RT_ENV_MAP_INTENSITY): the environment map the reference enables at compile time (config.h:36-38, main.cpp:28-31).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,6 +36,13 @@ int main(int argc, char **argv) {
     // *.txt: the scene-txt front end (BASELINE configs 1-2; no parser at the reference's HEAD), anything else: glTF (main.cpp:27)
     if (rt_scene_load(argv[1], static_cast<float>(width) / height, &loaded) != RT_OK)
         return die("load");
+    if (const char *env_map = std::getenv("RT_ENV_MAP")) { // USE_ENV_MAP / ENV_MAP_PATH / ENV_MAP_INTENSITY, config.h:36-38
+        const char *k = std::getenv("RT_ENV_MAP_INTENSITY");
+        if (rt_loaded_set_env_map(loaded, env_map, k ? std::strtof(k, nullptr) : 1.0f) != RT_OK) {
+            rt_loaded_free(loaded);
+            return die("environment map");
+        }
+    }
     const char *dev_env = std::getenv("RT_DEVICE");
     rt_scene *scene = nullptr;
     const int device = dev_env ? std::atoi(dev_env) : (rt_device_count() > 1 ? RT_ALL_DEVICES : 0);

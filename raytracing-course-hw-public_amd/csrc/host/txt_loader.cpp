@@ -254,6 +254,7 @@ void load_txt(const std::string &path, rt_loaded_scene &res) {
     d.textures = nullptr;
     d.camera = cam;
     std::memcpy(d.bg_color, bg, 12);
+    d.bg_texture = RT_TEX_NONE;
     d.ray_depth = ray_depth;
     d.n_primitives = (uint32_t)res.primitives.size();
     d.primitives = res.primitives.data();

@@ -1170,6 +1170,19 @@ DEV V3 pbr_brdf(V3 in_dir, V3 out_dir, const Surf &ii) { // :300-343
     return res;
 }
 
+// Scene::bg_at (scene.h:83-89): bg_color * bg.sample({x, y}, 2.2f).rgb(). With the default 1x1 WHITE_TEXTURE (USE_ENV_MAP = false,
+// config.h:37) Texture::sample returns its only texel before looking at the coordinates, so nothing is evaluated. With an environment
+// map the direction goes through the reference's own atan2f / asinf (rt_devspec.h rt_bg_uv) and the ordinary texture lookup with gamma.
+// ENV = false compiles the lookup out (wf_shade's default instantiations keep their register budget; the launcher picks ENV by scene).
+template <bool STATS, bool ENV = true> DEV V3 bg_at(const DevScene &S, V3 dir, const float *s_lin, const float *s_gam, LaneStats<STATS> &st) {
+    if (!ENV || S.bg_tex < 0)
+        return ld3(S.bg) * mk(1, 1, 1);
+    float u, v;
+    rt_bg_uv(dir.x, dir.y, dir.z, &u, &v);
+    const C4 c = tex_sample<STATS>(S, S.bg_tex, TEX_DEFAULT_WHITE, u, v, true, s_lin, s_gam, st);
+    return ld3(S.bg) * mk(c.r, c.g, c.b);
+}
+
 // ---------------------------------------------------------------------------------------------- one shade() level
 // trace_ray's hit / miss branch (raytracer.h:602-604) + shade (raytracer.h:555-591) for ONE cast result, without the
 // recursion: the caller owns depth bookkeeping and the (emission, scale) fold stack.
@@ -1181,7 +1194,7 @@ struct ShadeResult {
     bool terminal, push;
     V3 term, emission, scl, nro, nrd;
 };
-template <class R, bool STATS, class STK>
+template <class R, bool STATS, bool ENV = true, class STK>
 DEV ShadeResult shade_hit(const DevScene &S, const LightTabs &LT, const Hit &h, V3 ro, V3 rd, R &rng, bool has_lights, STK &stk, const float *s_lin,
                           const float *s_gam, LaneStats<STATS> &st) {
     ShadeResult out;
@@ -1191,7 +1204,7 @@ DEV ShadeResult shade_hit(const DevScene &S, const LightTabs &LT, const Hit &h, 
     out.nrd = mk(0, 0, 1);
     if (h.k == RT_NONE) {
         out.terminal = true;
-        out.term = ld3(S.bg) * mk(1, 1, 1); // Scene::bg_at with the 1x1 white bg (scene.h:83-89)
+        out.term = bg_at<STATS, ENV>(S, rd, s_lin, s_gam, st);
         return out;
     }
     const Surf ii = make_surf<STATS>(S, h, ro, rd, s_lin, s_gam, st);

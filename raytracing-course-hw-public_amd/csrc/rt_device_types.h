@@ -144,6 +144,8 @@ struct DevScene {
     const rt_primitive_desc *prims; // analytic primitives of the scene-txt front end (include/rt_primspec.h), brute force
     uint32_t n_prims;
     uint32_t n_triangles;           // scene.objects.size(): rt_cast_rays reports analytic primitive i as n_triangles + i
+    int32_t bg_tex;                 // Scene::bg (scene.h:81): view of the environment map in `textures`, -1 = the 1x1 WHITE_TEXTURE default
+    uint32_t pad_bg;
 };
 
 struct DevStats { // device-side counters, see rt_stats in include/rt_abi.h

@@ -42,6 +42,7 @@ struct EventPool {
 hipError_t launch_render(const DevScene &S, const RenderLaunch &L, bool stats, int blocks, hipStream_t stream);
 hipError_t launch_cast(const DevScene &S, const float *rays, uint32_t n, uint32_t *prim, float *bct, hipStream_t stream);
 hipError_t launch_light_pdf(const DevScene &S, const float *rays, uint32_t n, float *pdf, hipStream_t stream);
+hipError_t launch_bg_at(const DevScene &S, const float *dirs, uint32_t n, float *rgb, hipStream_t stream);
 // rt_wavefront.hip: one pass (pixel tile x sample range) of the wavefront pipeline, stream-ordered
 // `extend_events` (optional): one (start, stop) event pair per wf_extend launch is taken from the pool and recorded on `stream`
 // `packet_census_out` (optional, host, 2 words): trips and lanes served of this pass's wf_extend_packet launch (0, 0 if it did not run)

@@ -258,10 +258,33 @@ __global__ __launch_bounds__(256) void light_pdf_kernel(const DevScene S, const 
     pdf_out[i] = S.lights.n_tris ? lights_pdf<false>(S, light_tabs_global(S), o, d, stk, st) : 0.0f;
 }
 
+// Scene::bg_at for explicit directions (rt_bg_at: the environment lookup on its own, for the parity tests)
+__global__ __launch_bounds__(256) void bg_at_kernel(const DevScene S, const float *dirs, uint32_t n, float *rgb_out) {
+    __shared__ float s_lin[256];
+    __shared__ float s_gam[256];
+    s_lin[threadIdx.x] = S.lut_linear[threadIdx.x];
+    s_gam[threadIdx.x] = S.lut_gamma[threadIdx.x];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    LaneStats<false> st;
+    const V3 c = bg_at<false>(S, ld3(dirs + 3ull * i), s_lin, s_gam, st);
+    rgb_out[3ull * i] = c.x;
+    rgb_out[3ull * i + 1] = c.y;
+    rgb_out[3ull * i + 2] = c.z;
+}
+
 } // namespace
 
 
 namespace rt {
+
+hipError_t launch_bg_at(const DevScene &S, const float *dirs, uint32_t n, float *rgb, hipStream_t stream) {
+    if (n == 0)
+        return hipSuccess;
+    return RT_LAUNCH_CHECKED(bg_at_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, dirs, n, rgb);
+}
 
 hipError_t launch_render(const DevScene &S, const RenderLaunch &L, bool stats, int blocks, hipStream_t stream) {
     dim3 grid(blocks), block(256);

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void wf_extend_prims(const DevScene S, const W
 // ------------------------------------------------------------------------------------------------ shade
 // LIGHTS_LDS: the light BVH (inner nodes, triangles, aux) is small enough (DevBvh::lds_inner) to be staged in LDS once per
 // block; bvh_mix_dist's sample and pdf then read it there: a dozen dependent L1 round trips per hit become LDS reads.
-template <bool STATS, bool LIGHTS_LDS> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD) void wf_shade(const DevScene S, const WfLaunch L) {
+template <bool STATS, bool LIGHTS_LDS, bool ENV> __global__ __launch_bounds__(256, RT_SHADE_WAVES_PER_SIMD) void wf_shade(const DevScene S, const WfLaunch L) {
     __shared__ float s_lin[256];
     __shared__ float s_gam[256];
     __shared__ uint32_t s_stack[STACK_LDS_DWORDS_FOR(RT_SHADE_LDS_DEPTH)];
@@ -528,7 +528,7 @@ template <bool STATS, bool LIGHTS_LDS> __global__ __launch_bounds__(256, RT_SHAD
             if (h.k != RT_NONE)
                 depth_left -= 1; // shade(..., max_depth - 1)
             SD_STAMP(SD_LOAD);
-            const ShadeResult sr = shade_hit<Rng<RT_RNG_DEVICE>, STATS>(S, LT, h, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), rng, has_lights, stk, s_lin, s_gam, st);
+            const ShadeResult sr = shade_hit<Rng<RT_RNG_DEVICE>, STATS, ENV>(S, LT, h, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), rng, has_lights, stk, s_lin, s_gam, st);
             SD_STAMP(SD_BRDF);
             bool terminal = sr.terminal;
             V3 term = sr.term;
@@ -873,15 +873,22 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
             (void)hipEventRecord(e1, stream);
         if (S.n_prims)
             WF_LAUNCH(wf_extend_prims, dim3(shade_blocks), block, 0, stream, S, L);
-        const bool lights_lds = S.lights.lds_inner != 0u;
-        if (stats && lights_lds)
-            WF_LAUNCH((wf_shade<true, true>), dim3(shade_blocks), block, 0, stream, S, L);
+        // ENV: the scene has an environment map (DevScene::bg_tex): the miss branch looks it up (scene.h:83-89); those instantiations read the
+        // light tables from global memory (LIGHTS_LDS only saves latency), so a scene without one never pays for the lookup's registers
+        const bool env = S.bg_tex >= 0;
+        const bool lights_lds = S.lights.lds_inner != 0u && !env;
+        if (env && stats)
+            WF_LAUNCH((wf_shade<true, false, true>), dim3(shade_blocks), block, 0, stream, S, L);
+        else if (env)
+            WF_LAUNCH((wf_shade<false, false, true>), dim3(shade_blocks), block, 0, stream, S, L);
+        else if (stats && lights_lds)
+            WF_LAUNCH((wf_shade<true, true, false>), dim3(shade_blocks), block, 0, stream, S, L);
         else if (stats)
-            WF_LAUNCH((wf_shade<true, false>), dim3(shade_blocks), block, 0, stream, S, L);
+            WF_LAUNCH((wf_shade<true, false, false>), dim3(shade_blocks), block, 0, stream, S, L);
         else if (lights_lds)
-            WF_LAUNCH((wf_shade<false, true>), dim3(shade_blocks), block, 0, stream, S, L);
+            WF_LAUNCH((wf_shade<false, true, false>), dim3(shade_blocks), block, 0, stream, S, L);
         else
-            WF_LAUNCH((wf_shade<false, false>), dim3(shade_blocks), block, 0, stream, S, L);
+            WF_LAUNCH((wf_shade<false, false, false>), dim3(shade_blocks), block, 0, stream, S, L);
         WF_LAUNCH(wf_advance, dim3(1), dim3(64), 0, stream, L.counters, L.stripes);
         if (hs && b + 1 < L.ray_depth) { // size of queue b + 1 -> pinned word b + 1 (read by bounce b + 2)
             if ((e = hipMemcpyAsync(hs->counts + b + 1, L.counters + WF_CNT_IN, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)

@@ -64,6 +64,7 @@ class Scene:
     textures: List[np.ndarray] = field(default_factory=list)  # each (H,W,4) u8
     camera: Optional[Camera] = None
     bg_color: tuple = (1.0, 1.0, 1.0)
+    bg_texture: int = -1  # Scene::bg (scene.h:81): index into textures of the environment map, -1 = the 1x1 white default
     ray_depth: int = 8
     # analytic primitives of the scene-txt front end: dicts {kind, material_id, param[3], position[3], rotation xyzw[4]}
     primitives: List[dict] = field(default_factory=list)

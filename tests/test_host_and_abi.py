@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(rt):
     assert "rt_render" in names and "rt_create" in names and "rt_gltf_load" in names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ but not exported by librt_amd.so"
-    assert lib.rt_abi_version() == 2
+    assert lib.rt_abi_version() == 3
 
 
 def test_ctypes_prototypes_cover_the_headers(rt):
