@@ -41,6 +41,8 @@ _PROTOS = {
     "rto_minstd_below_sequence": (None, [C.c_uint32, C.c_uint32, C.c_uint32, _abi.c_u32_p]),
     "rto_sincos": (None, [_abi.c_float_p, C.c_uint32, _abi.c_float_p, _abi.c_float_p]),
     "rto_xoshiro_sequence": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _abi.c_float_p]),
+    "rto_xoshiro_raw": (None, [_abi.c_u32_p, C.c_uint32, _abi.c_u32_p]),
+    "rto_xoshiro_below_sequence": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _abi.c_u32_p]),
 }
 
 
@@ -157,6 +159,19 @@ def sincos(phi):
     c = np.zeros_like(phi)
     lib().rto_sincos(_abi.fptr(phi), phi.size, _abi.fptr(s), _abi.fptr(c))
     return s, c
+
+
+def xoshiro_raw(state, n):
+    st = np.ascontiguousarray(state, dtype=np.uint32)
+    out = np.zeros(n, dtype=np.uint32)
+    lib().rto_xoshiro_raw(_abi.u32ptr(st), n, _abi.u32ptr(out))
+    return out
+
+
+def xoshiro_below_sequence(seed, pixel, sample, bound, n):
+    out = np.zeros(n, dtype=np.uint32)
+    lib().rto_xoshiro_below_sequence(seed, pixel, sample, bound, n, _abi.u32ptr(out))
+    return out
 
 
 def xoshiro_sequence(seed, pixel, sample, n):

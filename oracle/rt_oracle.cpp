@@ -1073,6 +1073,20 @@ void rto_sincos(const float *phi, uint32_t n, float *s, float *c) {
     for (uint32_t i = 0; i < n; ++i)
         rt_sincos(phi[i], &s[i], &c[i]);
 }
+// raw engine outputs from an explicit state (known-answer test against the published xoshiro128++ vectors) and rt_xoshiro_below
+void rto_xoshiro_raw(const uint32_t state[4], uint32_t n, uint32_t *out) {
+    rt_xoshiro g;
+    for (int k = 0; k < 4; ++k)
+        g.s[k] = state[k];
+    for (uint32_t i = 0; i < n; ++i)
+        out[i] = rt_xoshiro_next(&g);
+}
+void rto_xoshiro_below_sequence(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bound, uint32_t n, uint32_t *out) {
+    rt_xoshiro g;
+    rt_xoshiro_seed(&g, seed, pixel, sample);
+    for (uint32_t i = 0; i < n; ++i)
+        out[i] = rt_xoshiro_below(&g, bound);
+}
 void rto_xoshiro_sequence(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float *out) {
     rt_xoshiro g;
     rt_xoshiro_seed(&g, seed, pixel, sample);

@@ -125,6 +125,54 @@ def test_xoshiro_streams(oracle):
     assert np.all(a * np.float32(2**24) == np.floor(a * np.float32(2**24)))  # exact multiples of 2^-24
 
 
+def test_xoshiro_against_published_vectors_and_an_independent_restatement(oracle):
+    """include/rt_devspec.h's xoshiro128++ is compiled into BOTH the kernels and the oracle, so "GPU == oracle" cannot tell whether it is
+    the published generator. Pinned here from outside: (a) the engine against the known answers of Blackman & Vigna's xoshiro128++ for the
+    state {1, 2, 3, 4} (the vector the public implementations test with), (b) seeding (splitmix64 of seed ^ (pixel, sample) * odd constant),
+    the 24-bit canonical float and the multiply-shift bounded integer against a restatement in plain Python integers."""
+    published = [641, 1573767, 3222811527, 3517856514, 836907274, 4247214768, 3867114732, 1355841295, 495546011, 621204420]
+    assert oracle.xoshiro_raw([1, 2, 3, 4], 10).tolist() == published
+    M32, M64 = (1 << 32) - 1, (1 << 64) - 1
+
+    def splitmix(x):
+        x = (x + 0x9E3779B97F4A7C15) & M64
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        return x, z ^ (z >> 31)
+
+    def rotl(v, k):
+        return ((v << k) | (v >> (32 - k))) & M32
+
+    def stream(seed, pixel, sample, n):
+        x = (seed ^ ((((pixel << 32) | sample) * 0xD1342543DE82EF95) & M64)) & M64
+        x, a = splitmix(x)
+        x, b = splitmix(x)
+        s = [a & M32, a >> 32, b & M32, b >> 32]
+        if not any(s):
+            s[0] = 1
+        out = []
+        for _ in range(n):
+            out.append((rotl((s[0] + s[3]) & M32, 7) + s[0]) & M32)
+            t = (s[1] << 9) & M32
+            s[2] ^= s[0]
+            s[3] ^= s[1]
+            s[1] ^= s[2]
+            s[0] ^= s[3]
+            s[2] ^= t
+            s[3] = rotl(s[3], 11)
+        return out
+
+    assert splitmix(1234567)[1] == 6457827717110365317  # splitmix64's published first output for this seed
+    for seed, pixel, sample in ((0, 0, 0), (1, 0, 0), (0xDEADBEEFCAFEF00D, 999999, 63), (7, 0xFFFFFFFF, 0xFFFFFFFF), (2**64 - 1, 123456, 999)):
+        raw = stream(seed, pixel, sample, 256)
+        got = oracle.xoshiro_sequence(seed, pixel, sample, 256)
+        want = np.array([(r >> 8) for r in raw], dtype=np.float64) * 2.0**-24
+        assert np.array_equal(got.astype(np.float64), want), (seed, pixel, sample)
+        for bound in (1, 2, 16, 40, 1000, 2**31 + 5):
+            assert oracle.xoshiro_below_sequence(seed, pixel, sample, bound, 256).tolist() == [(r * bound) >> 32 for r in raw], bound
+
+
 def test_shared_sincos_is_within_half_ulp_plus_epsilon(oracle):
     """rt_sincos evaluates in double and rounds once: within 0.5000001 ulp of the true value on [0, 2*pi]."""
     rng = np.random.default_rng(1)
