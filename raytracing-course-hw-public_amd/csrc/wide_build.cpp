@@ -457,7 +457,8 @@ extern "C" int rt_bvh_wide_build_host(const float *positions, uint32_t n_triangl
     if (nodes80) {
         if (nodes_capacity < w.nodes.size())
             return 1;
-        std::memcpy(nodes80, w.nodes.data(), w.nodes.size() * sizeof(WideNode));
+        if (!w.nodes.empty()) // an empty scene has no node: memcpy's source must not be null even for 0 bytes
+            std::memcpy(nodes80, w.nodes.data(), w.nodes.size() * sizeof(WideNode));
     }
     if (order_out && !w.order.empty())
         std::memcpy(order_out, w.order.data(), w.order.size() * sizeof(uint32_t));
