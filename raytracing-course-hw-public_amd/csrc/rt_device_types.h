@@ -211,7 +211,7 @@ struct WfLaunch {
                              // waves take contiguous positions, so a line of hits is filled by one wave within one chunk and
                              // leaves L2 as a full line (stored at the ray's own slot, sorted rays scattered 16-B stores over
                              // the whole array: 9x HBM write amplification, profiles/r02_write_amp.txt)
-    WfFold *fold;            // [n_paths][ray_depth]: pending shade() frames, a path's frames contiguous (its unwind reads 1-2 lines)
+    WfFold *fold;            // [ray_depth][n_paths]: pending shade() frames, level by level: wf_fold (one lane per path) reads each level coalesced
     RtF4 *sample_out;        // [n_paths]: sanitised radiance of each finished sample
     RtF4 *accum;             // [pass_pixels]: running per-pixel sum across sample passes (reference order)
     float *fb;               // width*height*3

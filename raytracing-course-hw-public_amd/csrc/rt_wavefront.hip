@@ -533,7 +533,7 @@ template <bool STATS, bool LIGHTS_LDS, bool ENV> __global__ __launch_bounds__(25
             bool terminal = sr.terminal;
             V3 term = sr.term;
             if (sr.push) { // emission + trace_ray(...) * scl (raytracer.h:588-590), folded when the path ends
-                float4 *fw = reinterpret_cast<float4 *>(L.fold + ((size_t)path * L.ray_depth + nb));
+                float4 *fw = reinterpret_cast<float4 *>(L.fold + ((size_t)nb * L.n_paths + path));
                 fw[0] = make_float4(sr.emission.x, sr.emission.y, sr.emission.z, 0.f);
                 fw[1] = make_float4(sr.scl.x, sr.scl.y, sr.scl.z, 0.f);
                 ++nb;
@@ -543,21 +543,10 @@ template <bool STATS, bool LIGHTS_LDS, bool ENV> __global__ __launch_bounds__(25
                 term = mk(0, 0, 0);
             }
             if (terminal) {
-                V3 res = term;
-                while (nb > 0) { // unwind the pending shade() frames: emission + inner * scl
-                    --nb;
-                    const float4 *fr = reinterpret_cast<const float4 *>(L.fold + ((size_t)path * L.ray_depth + nb));
-                    const float4 fe = fr[0], fs = fr[1];
-                    V3 clr = res * mk(fs.x, fs.y, fs.z);
-                    res = mk(fe.x, fe.y, fe.z) + clr;
-                }
-                if (isnan_f(res.x)) // sanitize_nans raytracer.h:607-616
-                    res.x = 0;
-                if (isnan_f(res.y))
-                    res.y = 0;
-                if (isnan_f(res.z))
-                    res.z = 0;
-                L.sample_out[path] = RtF4{res.x, res.y, res.z, 0.f};
+                // The pending shade() frames are folded by wf_fold after the last bounce, not here: at any bounce only about a
+                // quarter of a wave's paths end, each with its own number of frames, so the unwind ran at 16 of 64 lanes behind
+                // dependent loads (14 % of this kernel's cycles). Leave the innermost value and the frame count.
+                L.sample_out[path] = RtF4{term.x, term.y, term.z, __uint_as_float(nb)};
                 st.sample();
                 SD_STAMP(SD_FOLD);
             } else {
@@ -687,6 +676,32 @@ __global__ __launch_bounds__(64) void wf_advance(uint32_t *counters, uint32_t *s
         counters[WF_CNT_SLOTS] = (counters[WF_CNT_IN] + 63u) >> 6; // wave slots of the launch that just wrote the new in-queue
         counters[WF_CNT_IN] = incl;
         counters[WF_CNT_TICKET] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fold
+// The return path of the recursion (raytracer.h:588-590): every finished path's pending frames `emission + inner * scl`, innermost
+// first, then sanitize_nans (:607-616). One lane per path of the pass, all lanes busy; frames are stored level by level (WfLaunch::fold), so a
+// wave reads 2 KB of consecutive records per level and nothing it does not need.
+__global__ __launch_bounds__(256) void wf_fold(const WfLaunch L) {
+    for (uint32_t path = blockIdx.x * blockDim.x + threadIdx.x; path < L.n_paths; path += gridDim.x * blockDim.x) {
+        const RtF4 v = L.sample_out[path];
+        V3 res = mk(v.x, v.y, v.z);
+        uint32_t nb = __float_as_uint(v.w);
+        while (nb > 0) {
+            --nb;
+            const float4 *fr = reinterpret_cast<const float4 *>(L.fold + ((size_t)nb * L.n_paths + path)); // frame level nb: adjacent lanes, adjacent records
+            const float4 fe = fr[0], fs = fr[1];
+            const V3 clr = res * mk(fs.x, fs.y, fs.z);
+            res = mk(fe.x, fe.y, fe.z) + clr;
+        }
+        if (isnan_f(res.x))
+            res.x = 0;
+        if (isnan_f(res.y))
+            res.y = 0;
+        if (isnan_f(res.z))
+            res.z = 0;
+        L.sample_out[path] = RtF4{res.x, res.y, res.z, 0.f};
     }
 }
 
@@ -903,6 +918,7 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         L.paths_in = L.paths_out;
         L.paths_out = t;
     }
+    WF_LAUNCH(wf_fold, dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, L);
     const int res_blocks = (int)((L.pass_pixels + 255u) / 256u);
     WF_LAUNCH(wf_resolve, dim3(res_blocks > 0 ? res_blocks : 1), block, 0, stream, L, first_pass ? 1 : 0, last_pass ? 1 : 0);
     return hipSuccess;
