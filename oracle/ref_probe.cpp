@@ -11,6 +11,8 @@
 //   ref_probe bgat     <gltf> <W> <H> <image> <dirs.bin> <out.bin>  Scene::bg_at (scene.h:83-89) with scene.bg = load_img(image) as main.cpp:29-31
 //                                                          does under USE_ENV_MAP, for explicit directions (3 floats each) -> rgb
 //   ref_probe envrender <gltf> <W> <H> <image> <spp> <out.ppm>  main.cpp:27-43 with the environment map loaded: the reference's own render
+//   ref_probe sphere   <radius> 0 0 <rays.bin> <out.bin>   intersect_ray_sphere (raytracer.h:61-77, unused by the reference's render loop; the
+//                                                          scene-txt ELLIPSOID restates it): (t1, t2) per ray
 //   ref_probe texture  <image> 0 0 <out.bin>               geometry::Texture::load_img (the reference's stb_image build, 4 channels
 //                                                          forced, geometry.h:584-598): [width, height, texel floats r g b a ...]
 //
@@ -49,6 +51,21 @@ int main(int argc, char **argv) {
         return 2;
     }
     std::string mode = argv[1];
+    if (mode == "sphere") { // no scene involved: the reference's quadratic solve for a sphere of radius r at the origin
+        if (argc < 7)
+            return 2;
+        const float r = std::strtof(argv[2], nullptr);
+        auto f = read_floats(argv[5]);
+        std::vector<uint32_t> o;
+        for (size_t i = 0; i + 5 < f.size(); i += 6) {
+            geometry::ray ray{{f[i], f[i + 1], f[i + 2]}, {f[i + 3], f[i + 4], f[i + 5]}};
+            auto [t1, t2] = intersect_ray_sphere(ray, r);
+            put_f32(o, t1);
+            put_f32(o, t2);
+        }
+        write_words(argv[6], o);
+        return 0;
+    }
     if (mode == "texture") { // no scene involved: what the reference's image decoder returns for one file
         std::vector<uint32_t> o;
         try {

@@ -139,3 +139,21 @@ def test_cli_renders_a_scene_txt(gpu, oracle, tmp_path):
     bad.write_text("NEW_PRIMITIVE\nTORUS 1 2\n")
     r = subprocess.run([os.path.join(root, "run.sh"), str(bad), "8", "8", "1", str(out)], capture_output=True, text=True, env=env)
     assert r.returncode == 1 and "unknown command 'TORUS'" in r.stderr
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_device_ellipsoid_solve_is_the_reference_sphere_routine(gpu, sg, k):
+    """The device's analytic-primitive kernel against the reference's own intersect_ray_sphere (raytracer.h:61-77) for spheres at the origin:
+    the same known answers the oracle is held to in tests/test_scene_txt.py, without the oracle in between."""
+    from test_scene_txt import sphere_kat_check
+
+    kat = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sphere_kat.npz"))
+
+    def cast(scene, rays):
+        dev = gpu.DeviceScene(scene)
+        try:
+            return dev.cast_rays(rays)
+        finally:
+            dev.close()
+
+    sphere_kat_check(cast, sg, kat, k)

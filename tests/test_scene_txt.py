@@ -166,3 +166,45 @@ def test_reference_sample_data_parses_if_present(rt, oracle):
             assert a["positions"].shape[0] == 12 and [p["kind"] for p in a["primitives"]] == [1, 2]
             fb, st = oracle.OracleScene(ls).run_raytracer(256, 256, 4, rng_mode=rt.RT_RNG_REFERENCE)
             assert st["samples"] == 256 * 256 * 4 and np.isfinite(fb).all() and 0 < fb.mean() < 1
+
+
+def _sphere_scene(sg, radius):
+    """No triangles, one ELLIPSOID with equal semi-axes at the origin, identity rotation."""
+    mat = sg.Material(color=(0.8, 0.8, 0.8, 1.0), emission=(0.0, 0.0, 0.0))
+    z = np.zeros((0, 3, 3), dtype=np.float32)
+    return sg.Scene(positions=z, normals=z, texcoords=np.zeros((0, 3, 2), dtype=np.float32), tangents=z, material_ids=np.zeros(0, dtype=np.uint32), materials=[mat],
+                    camera=sg.look_camera((0.0, 0.0, 5.0), yaw_deg=0.0, yfov=0.8),
+                    primitives=[dict(kind=1, material_id=0, param=(radius,) * 3, position=(0.0, 0.0, 0.0), rotation=(0.0, 0.0, 0.0, 1.0))])
+
+
+def sphere_kat_check(cast, sg, kat, k):
+    """cast(scene, rays) -> (prim, bct). The primitive's distance is the reference function's first root >= EPS (raytracer.h:61-77), bit for bit."""
+    EPS = np.float32(1e-4)
+    rays, radius, t12 = kat[f"rays_{k}"], float(kat[f"radius_{k}"]), kat[f"t_{k}"]
+    prim, bct = cast(_sphere_scene(sg, radius), rays)
+    t1, t2 = t12[:, 0], t12[:, 1]
+    use1 = t1 >= EPS
+    use2 = ~use1 & (t2 >= EPS)
+    want_hit = use1 | use2
+    want_t = np.where(use1, t1, t2)
+    assert np.array_equal(prim != 0xFFFFFFFF, want_hit), int(((prim != 0xFFFFFFFF) != want_hit).sum())
+    got_t = bct[:, 2]
+    assert np.array_equal(got_t[want_hit].view(np.uint32), want_t[want_hit].view(np.uint32))
+    assert want_hit.sum() > 1000 and use2.sum() > 300 and (~want_hit).sum() > 1000  # outside hits, inside hits, misses all present
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_ellipsoid_solve_is_the_reference_sphere_routine(rt, sg, oracle, k):
+    """The ELLIPSOID's quadratic solve restates the reference's (unused) intersect_ray_sphere, raytracer.h:61-77: for a sphere at the origin
+    its distance is that function's root, bit for bit (tests/golden/sphere_kat.npz, computed BY the reference function through ref_probe).
+    This pins the solver; translation, rotation, root choice and normal remain definitions of include/rt_primspec.h."""
+    kat = np.load(os.path.join(GOLD, "sphere_kat.npz"))
+
+    def cast(scene, rays):
+        orc = oracle.OracleScene(scene)
+        try:
+            return orc.cast_rays(rays)
+        finally:
+            orc.close()
+
+    sphere_kat_check(cast, sg, kat, k)
