@@ -59,14 +59,15 @@ enum {
 };
 
 /* RNG / transcendental policy of the sample loop.
- *   RT_RNG_DEVICE : counter-seeded xoshiro128++ stream per (pixel, sample) + shared double-precision
- *                   sin/cos polynomial (include/rt_devspec.h). Scheduling independent: any tiling / GPU
- *                   count gives the same framebuffer. This is the production mode.
+ *   RT_RNG_DEVICE : counter-seeded xoshiro128++ stream per (pixel, sample) (include/rt_devspec.h). Scheduling
+ *                   independent: any tiling / GPU count gives the same framebuffer. This is the production mode.
  *   RT_RNG_REFERENCE : the reference's stream: std::minstd_rand seeded with the 256-pixel span index
  *                   (raytracer.h:458,648; config.h:13) and the libstdc++-11 distribution algorithms,
  *                   one sequential stream per span. On the GPU one lane walks one span (parity mode,
- *                   not a performance mode). sin/cos are glibc's sinf / cosf restated bit for bit
- *                   (rt_devspec.h rt_sincos_libm): the image is the reference binary's, byte for byte.
+ *                   not a performance mode): the image is the reference binary's, byte for byte.
+ * Everything else is the reference's arithmetic in both modes, transcendentals included: sin / cos of the sampled
+ * azimuths are glibc's sinf / cosf restated bit for bit (rt_devspec.h rt_sincos_libm, compared with libm on every
+ * float of [0, 2 pi]); the modes differ in the random stream only.
  */
 enum { RT_RNG_DEVICE = 0, RT_RNG_REFERENCE = 1 };
 

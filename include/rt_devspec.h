@@ -9,11 +9,9 @@
  *   2. rt_minstd   : std::minstd_rand + the libstdc++-11 uniform_real<float> / uniform_int<int> algorithms
  *                    (bits/random.tcc generate_canonical; bits/uniform_int_dist.h:277-330, the two-division
  *                    "fallback" downscaling branch), used in RT_RNG_REFERENCE mode.
- *   3. rt_sincos   : sin/cos of an angle in [0, 2*pi] evaluated in double precision (Cody-Waite quadrant
- *                    reduction + Taylor/minimax polynomials) and rounded once to float: RT_RNG_DEVICE mode's
- *                    definition of sin/cos ("Hop 2").
- *   4. rt_sincos_libm : glibc's sinf / cosf restated bit for bit, which is what the reference's std::sin / std::cos
- *                    (raytracer.h:104,158-159) evaluate: RT_RNG_REFERENCE mode on the device.
+ *   3. rt_sincos_libm : glibc's sinf / cosf restated bit for bit, which is what the reference's std::sin / std::cos
+ *                    (raytracer.h:104,158-159) evaluate; used by the device in BOTH RNG modes (the oracle calls libm itself).
+ *   4. rt_atan2f_libm / rt_asinf_libm / rt_bg_uv : glibc's atan2f / asinf, for Scene::bg_at (scene.h:83-89).
  *
  * Only +,-,*,/ on float/double and integer ops are used; with floating-point contraction disabled
  * (-ffp-contract=off, both compilers) the results are bit-identical on x86-64 and gfx950.
@@ -118,53 +116,6 @@ RT_HD uint32_t rt_minstd_below(rt_minstd *g, uint32_t n) {
 }
 
 /* ---------------------------------------------------------------- sin / cos ---- */
-/* Inputs are the sampled azimuths of raytracer.h:102 and :157, i.e. phi in [0, 2*pi] (float). Any finite
- * input up to a few thousand is still reduced correctly; larger / non-finite inputs are not needed. */
-RT_HD void rt_sincos(float phi, float *s_out, float *c_out) {
-    const double x = (double)phi;
-    const double two_over_pi = 0.63661977236758134308;
-    const double pio2_hi = 1.57079632673412561417e+00; /* first 33 bits of pi/2 */
-    const double pio2_lo = 6.07710050650619224932e-11; /* pi/2 - pio2_hi */
-    /* k = nearest integer to x*2/pi for x >= 0 */
-    const double kd = (double)(int)(x * two_over_pi + 0.5);
-    const int k = (int)kd;
-    const double r = (x - kd * pio2_hi) - kd * pio2_lo;
-    const double z = r * r;
-    /* sin(r), |r| <= pi/4 + eps : r + r^3 * S(z) */
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    const double sp = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
-    const double sr = r + (r * z) * sp;
-    const double cp = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
-    const double cr = (1.0 - 0.5 * z) + (z * z) * cp;
-    double s, c;
-    switch (k & 3) {
-    case 0:
-        s = sr;
-        c = cr;
-        break;
-    case 1:
-        s = cr;
-        c = -sr;
-        break;
-    case 2:
-        s = -sr;
-        c = -cr;
-        break;
-    default:
-        s = -cr;
-        c = sr;
-        break;
-    }
-    *s_out = (float)s;
-    *c_out = (float)c;
-}
-
-/* ---------------------------------------------------------------- sin / cos, the reference's own ---- */
 /* The reference calls std::sin / std::cos on floats (raytracer.h:104,158-159): glibc's sinf / cosf. In RT_RNG_REFERENCE mode the
  * device evaluates THAT function: glibc 2.35 sysdeps/ieee754/flt-32/{s_sinf.c, s_cosf.c, sincosf.h} (the ARM Optimized Routines
  * algorithm: double-precision arithmetic, reduction by multiples of pi/2 with a 2^24-scaled 2/pi, two polynomials), restated with
@@ -173,16 +124,18 @@ RT_HD void rt_sincos(float phi, float *s_out, float *c_out) {
  * function with the host libm on EVERY float in [0, 2*pi] (1 086 918 636 values, both with and without contraction of the
  * multiply-adds: the final rounding to float absorbs the difference) — run by the CPU suite. With it the GPU's reference-RNG
  * render is the reference binary's image byte for byte, not merely the oracle's. */
-RT_HD float rt_libm_poly(double x, double x2, double cs, int n) { /* sinf_poly; cs = +1: table entry 0, -1: entry 1 (cosine coefficients negated) */
-    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+/* sinf_poly's two branches: the sine polynomial in x (sign applied by the caller) and the cosine polynomial, whose coefficients the second
+ * table entry negates (cs = -1) */
+RT_HD float rt_libm_sin_poly(double x, double x2) {
     const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
-    if ((n & 1) == 0) {
-        const double x3 = x * x2;
-        const double s1 = S2 + x2 * S3;
-        const double x7 = x3 * x2;
-        const double s = x + x3 * S1;
-        return (float)(s + x7 * s1);
-    }
+    const double x3 = x * x2;
+    const double s1 = S2 + x2 * S3;
+    const double x7 = x3 * x2;
+    const double s = x + x3 * S1;
+    return (float)(s + x7 * s1);
+}
+RT_HD float rt_libm_cos_poly(double x2, double cs) {
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
     const double x4 = x2 * x2;
     const double c2 = cs * C3 + x2 * (cs * C4);
     const double c1 = cs * C0 + x2 * (cs * C1);
@@ -199,25 +152,19 @@ RT_HD void rt_sincos_libm(float y, float *s_out, float *c_out) {
     b.f = y;
     const uint32_t top12 = (b.u >> 20) & 0x7ffu; /* abstop12 */
     double x = (double)y;
-    if (top12 < 0x3f4u) {      /* abstop12(y) < abstop12(pio4): |y| < 0.75 */
-        if (top12 < 0x398u) {  /* |y| < 2^-12 */
-            *s_out = y;
-            *c_out = 1.0f;
-            return;
-        }
-        const double x2 = x * x;
-        *s_out = rt_libm_poly(x, x2, 1.0, 0);
-        *c_out = rt_libm_poly(x, x2, 1.0, 1);
-        return;
-    }
-    /* reduce_fast: n = round(x * 2/pi) through the 2^24-scaled product, x -= n * pi/2 */
+    /* reduce_fast: n = round(x * 2/pi) through the 2^24-scaled product, x -= n * pi/2. glibc skips it below pi/4-ish (|y| < 0.75), where it
+     * yields n = 0 and leaves x alone: one straight-line path serves both (no divergence between the lanes of a wave). */
     const double r = x * HPI_INV;
     const int n = ((int32_t)r + 0x800000) >> 24;
     x = x - (double)n * HPI;
     const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0; /* sign[n & 3] = {1, -1, -1, 1} */
     const double cs = (n & 2) ? -1.0 : 1.0;
-    *s_out = rt_libm_poly(x * sgn, x * x, cs, n);
-    *c_out = rt_libm_poly(x * sgn, x * x, cs, n ^ 1);
+    /* sinf_poly (x * sgn, x * x, table entry, n) gives the sine for even n and the cosine for odd n; cosf asks for n + 1: each polynomial once */
+    const float ps = rt_libm_sin_poly(x * sgn, x * x), pc = rt_libm_cos_poly(x * x, cs);
+    const int even = (n & 1) == 0;
+    const int tiny = top12 < 0x398u; /* |y| < 2^-12: sinf returns y, cosf returns 1 */
+    *s_out = tiny ? y : (even ? ps : pc);
+    *c_out = tiny ? 1.0f : (even ? pc : ps);
 }
 
 /* ---------------------------------------------------------------- atan2 / asin, the reference's own ---- */

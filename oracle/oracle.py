@@ -30,7 +30,7 @@ _lib = None
 _PROTOS = {
     "rto_create": (C.c_int, [C.POINTER(_abi.RtSceneDesc), C.POINTER(C.c_void_p)]),
     "rto_destroy": (None, [C.c_void_p]),
-    "rto_render": (C.c_int, [C.c_void_p, C.POINTER(_abi.RtParams), _abi.c_float_p, C.POINTER(_abi.RtStats), C.c_int, C.c_int]),
+    "rto_render": (C.c_int, [C.c_void_p, C.POINTER(_abi.RtParams), _abi.c_float_p, C.POINTER(_abi.RtStats), C.c_int]),
     "rto_cast_rays": (C.c_int, [C.c_void_p, _abi.c_float_p, C.c_uint32, _abi.c_u32_p, _abi.c_float_p]),
     "rto_light_pdf": (C.c_int, [C.c_void_p, _abi.c_float_p, C.c_uint32, _abi.c_float_p]),
     "rto_bg_at": (C.c_int, [C.c_void_p, _abi.c_float_p, C.c_uint32, _abi.c_float_p]),
@@ -40,6 +40,7 @@ _PROTOS = {
     "rto_minstd_sequence": (None, [C.c_uint32, C.c_uint32, _abi.c_float_p]),
     "rto_minstd_below_sequence": (None, [C.c_uint32, C.c_uint32, C.c_uint32, _abi.c_u32_p]),
     "rto_sincos": (None, [_abi.c_float_p, C.c_uint32, _abi.c_float_p, _abi.c_float_p]),
+    "rto_libm_sincos": (None, [_abi.c_float_p, C.c_uint32, _abi.c_float_p, _abi.c_float_p]),
     "rto_xoshiro_sequence": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _abi.c_float_p]),
     "rto_xoshiro_raw": (None, [_abi.c_u32_p, C.c_uint32, _abi.c_u32_p]),
     "rto_xoshiro_below_sequence": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _abi.c_u32_p]),
@@ -93,15 +94,13 @@ class OracleScene:
             pass
 
     def run_raytracer(self, width, height, samples, rng_mode=_abi.RT_RNG_DEVICE, seed=0, shard_index=0, shard_count=1,
-                      shard_block=0, threads=0, libm_sincos=None, out=None):
-        """CPU restatement of run_raytracer (raytracer.h:629). libm_sincos defaults to True in reference-RNG
-        mode (byte parity with the reference binary) and False in device-RNG mode (parity with the HIP path)."""
-        if libm_sincos is None:
-            libm_sincos = rng_mode == _abi.RT_RNG_REFERENCE
+                      shard_block=0, threads=0, out=None):
+        """CPU restatement of run_raytracer (raytracer.h:629): the reference's arithmetic (libm included) in both RNG modes; the
+        modes differ in the random stream only."""
         p = _abi.RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block, 0)
         st = _abi.RtStats()
         fb = out if out is not None else np.zeros((height, width, 3), dtype=np.float32)
-        _check(lib().rto_render(self._h, C.byref(p), _abi.fptr(fb), C.byref(st), int(threads), int(bool(libm_sincos))))
+        _check(lib().rto_render(self._h, C.byref(p), _abi.fptr(fb), C.byref(st), int(threads)))
         return fb, st.as_dict()
 
     def cast_rays(self, rays):
@@ -153,11 +152,13 @@ def minstd_below_sequence(seed, bound, n):
     return out
 
 
-def sincos(phi):
+def sincos(phi, libm=False):
+    """(sin, cos) of float32 angles: the restatement the device evaluates (include/rt_devspec.h rt_sincos_libm), or with libm=True the
+    host libm's sinf / cosf, which is what the oracle's render loop calls."""
     phi = np.ascontiguousarray(phi, dtype=np.float32)
     s = np.zeros_like(phi)
     c = np.zeros_like(phi)
-    lib().rto_sincos(_abi.fptr(phi), phi.size, _abi.fptr(s), _abi.fptr(c))
+    (lib().rto_libm_sincos if libm else lib().rto_sincos)(_abi.fptr(phi), phi.size, _abi.fptr(s), _abi.fptr(c))
     return s, c
 
 

@@ -534,24 +534,19 @@ template <class R> inline float uniform_real(R &r, float a, float b) { return r.
 template <class R> struct Integrator {
     const rto_scene &sc;
     R rng;
-    bool libm_sincos;
     Counters c;
     unsigned width, height, samples;
     float tan_x, tan_y;
 
-    Integrator(const rto_scene &s, unsigned w, unsigned h, unsigned spp, bool libm) : sc(s), libm_sincos(libm), width(w), height(h), samples(spp) {
+    Integrator(const rto_scene &s, unsigned w, unsigned h, unsigned spp) : sc(s), width(w), height(h), samples(spp) {
         // raytracer.h:531-535 + Camera::fov_y scene.h:69-71 (float overloads)
         tan_x = std::tan(sc.cam.fov_x / 2);
         float fov_y = std::atan(std::tan(sc.cam.fov_x / 2) * height / width) * 2;
         tan_y = std::tan(fov_y / 2);
     }
-    void sincos(float phi, float &s, float &co) {
-        if (libm_sincos) {
-            co = std::cos(phi);
-            s = std::sin(phi);
-        } else {
-            rt_sincos(phi, &s, &co);
-        }
+    void sincos(float phi, float &s, float &co) { // raytracer.h:104,158-159: std::cos / std::sin on floats (glibc cosf / sinf)
+        co = std::cos(phi);
+        s = std::sin(phi);
     }
     bool coin(float rate) { return uniform_real(rng, 0.0f, 1.0f) <= rate; } // raytracer.h:486-489
 
@@ -817,7 +812,7 @@ bool block_selected(const rt_params &p, size_t pixel) {
 }
 
 // raytracer.h:629-674
-template <class R> void run_raytracer(const rto_scene &sc, const rt_params &p, float *fb, Counters &total, int threads, bool libm) {
+template <class R> void run_raytracer(const rto_scene &sc, const rt_params &p, float *fb, Counters &total, int threads) {
     size_t n_pix = (size_t)p.width * p.height;
     int span_count = (int)((n_pix + SPAN_SIZE - 1) / SPAN_SIZE);
     std::atomic_int next_span(0);
@@ -830,7 +825,7 @@ template <class R> void run_raytracer(const rto_scene &sc, const rt_params &p, f
                 size_t begin = SPAN_SIZE * span, end = std::min(begin + SPAN_SIZE, n_pix);
                 if (!block_selected(p, begin))
                     continue;
-                Integrator<R> it(sc, p.width, p.height, p.samples, libm);
+                Integrator<R> it(sc, p.width, p.height, p.samples);
                 if constexpr (std::is_same_v<R, RngMinstd>)
                     rt_minstd_seed(&it.rng.g, (uint32_t)span); // RaytracerThreadContext(ctx, span) :648
                 for (size_t p_idx = begin; p_idx < end; ++p_idx) {
@@ -935,8 +930,8 @@ int rto_create(const rt_scene_desc *d, rto_scene **out) {
 
 void rto_destroy(rto_scene *s) { delete s; }
 
-// threads <= 0 -> hardware_concurrency (raytracer.h:636). libm_sincos: 1 = glibc sinf/cosf (reference), 0 = rt_sincos.
-int rto_render(rto_scene *s, const rt_params *p, float *fb, rt_stats *stats, int threads, int libm_sincos) {
+// threads <= 0 -> hardware_concurrency (raytracer.h:636)
+int rto_render(rto_scene *s, const rt_params *p, float *fb, rt_stats *stats, int threads) {
     if (!s || !p || !fb || p->width == 0 || p->height == 0) {
         g_err = "rto_render: bad arguments";
         return RT_ERR_INVALID_ARG;
@@ -952,9 +947,9 @@ int rto_render(rto_scene *s, const rt_params *p, float *fb, rt_stats *stats, int
     Counters c;
     auto t0 = std::chrono::steady_clock::now();
     if (p->rng_mode == RT_RNG_REFERENCE)
-        run_raytracer<RngMinstd>(*s, *p, fb, c, threads, libm_sincos != 0);
+        run_raytracer<RngMinstd>(*s, *p, fb, c, threads);
     else
-        run_raytracer<RngXoshiro>(*s, *p, fb, c, threads, libm_sincos != 0);
+        run_raytracer<RngXoshiro>(*s, *p, fb, c, threads);
     auto t1 = std::chrono::steady_clock::now();
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
@@ -1001,7 +996,7 @@ int rto_cast_rays(rto_scene *s, const float *rays, uint32_t n, uint32_t *prim_ou
 
 int rto_light_pdf(rto_scene *s, const float *rays, uint32_t n, float *pdf_out) {
     rt_params dummy{};
-    Integrator<RngXoshiro> it(*s, 1, 1, 1, false);
+    Integrator<RngXoshiro> it(*s, 1, 1, 1);
     (void)dummy;
     for (uint32_t i = 0; i < n; ++i) {
         V3 x{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, d{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
@@ -1011,7 +1006,7 @@ int rto_light_pdf(rto_scene *s, const float *rays, uint32_t n, float *pdf_out) {
 }
 
 int rto_bg_at(rto_scene *s, const float *dirs, uint32_t n, float *rgb_out) {
-    Integrator<RngXoshiro> it(*s, 1, 1, 1, false);
+    Integrator<RngXoshiro> it(*s, 1, 1, 1);
     for (uint32_t i = 0; i < n; ++i) {
         V3 c = it.bg_at({dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]});
         rgb_out[3 * i] = c.x, rgb_out[3 * i + 1] = c.y, rgb_out[3 * i + 2] = c.z;
@@ -1069,9 +1064,15 @@ void rto_minstd_below_sequence(uint32_t seed, uint32_t bound, uint32_t n, uint32
     for (uint32_t i = 0; i < n; ++i)
         out[i] = rt_minstd_below(&g, bound);
 }
-void rto_sincos(const float *phi, uint32_t n, float *s, float *c) {
+void rto_sincos(const float *phi, uint32_t n, float *s, float *c) { // the restatement the DEVICE evaluates (rt_devspec.h), for the CPU tests
     for (uint32_t i = 0; i < n; ++i)
-        rt_sincos(phi[i], &s[i], &c[i]);
+        rt_sincos_libm(phi[i], &s[i], &c[i]);
+}
+void rto_libm_sincos(const float *phi, uint32_t n, float *s, float *c) { // what the oracle itself calls
+    for (uint32_t i = 0; i < n; ++i) {
+        s[i] = std::sin(phi[i]);
+        c[i] = std::cos(phi[i]);
+    }
 }
 // raw engine outputs from an explicit state (known-answer test against the published xoshiro128++ vectors) and rt_xoshiro_below
 void rto_xoshiro_raw(const uint32_t state[4], uint32_t n, uint32_t *out) {

@@ -160,15 +160,11 @@ template <> struct Rng<RT_RNG_DEVICE> {
     rt_xoshiro g;
     DEV float canonical() { return rt_xoshiro_canonical(&g); }
     DEV uint32_t below(uint32_t n) { return rt_xoshiro_below(&g, n); }
-    DEV static void sincos(float phi, float *s, float *c) { rt_sincos(phi, s, c); }
 };
 template <> struct Rng<RT_RNG_REFERENCE> {
     rt_minstd g;
     DEV float canonical() { return rt_minstd_canonical(&g); }
     DEV uint32_t below(uint32_t n) { return rt_minstd_below(&g, n); }
-    // the reference binary's std::sin / std::cos on float = glibc sinf / cosf: restated bit for bit (rt_devspec.h,
-    // proved over all of [0, 2 pi] by tools/proofs/sincosf_exhaustive.c), so this mode reproduces the binary's image
-    DEV static void sincos(float phi, float *s, float *c) { rt_sincos_libm(phi, s, c); }
 };
 // std::uniform_real_distribution<float>(a, b)(rng) = canonical * (b - a) + a
 template <class R> DEV float uniform_real(R &r, float a, float b) { return r.canonical() * (b - a) + a; }
@@ -1085,7 +1081,7 @@ template <class R> DEV V3 sphere_uniform(R &rng) { // raytracer.h:94-105
     float co_z = __builtin_sqrtf(rmax(0.0f, 1 - z * z));
     float phi = uniform_real(rng, 0.0f, 2 * PI_F);
     float s, c;
-    R::sincos(phi, &s, &c);
+    rt_sincos_libm(phi, &s, &c); // std::cos / std::sin on floats = glibc cosf / sinf, restated bit for bit (rt_devspec.h)
     return {co_z * c, co_z * s, z};
 }
 DEV V3 halfway(V3 in_dir, V3 out_dir) { return norm(out_dir - in_dir); } // :131-134
@@ -1110,7 +1106,7 @@ template <class R> DEV V3 vndf_sample(R &rng, float roughness, V3 in_dir, V3 nor
     float r = __builtin_sqrtf(uniform_real(rng, 0, 1));
     float phi = 2.0f * PI_F * uniform_real(rng, 0, 1);
     float sn, cs;
-    R::sincos(phi, &sn, &cs);
+    rt_sincos_libm(phi, &sn, &cs);
     float t1 = r * cs;
     float t2 = r * sn;
     float s = 0.5f * (1.0f + vh.z);

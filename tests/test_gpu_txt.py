@@ -88,7 +88,7 @@ def test_txt_scene_matches_oracle(gpu, oracle, name):
             dev.run_raytracer(W, H, SPP, seed=31, shard_index=r, shard_count=3, shard_block=256, out=sh)
         assert np.array_equal(sh.view(np.uint32), ofb.view(np.uint32))
         rfb, _ = dev.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE)
-        orf, _ = orc.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE, libm_sincos=True)
+        orf, _ = orc.run_raytracer(W, H, 2, rng_mode=gpu.RT_RNG_REFERENCE)
         assert np.array_equal(rfb.view(np.uint32), orf.view(np.uint32))
         if name == "boxes_only":  # ... and the reference binary's own bytes for this scene (tests/test_scene_txt.py pins the fixture)
             img, _ = dev.run_raytracer_rgb8(64, 48, 4, rng_mode=gpu.RT_RNG_REFERENCE)

@@ -173,15 +173,18 @@ def test_xoshiro_against_published_vectors_and_an_independent_restatement(oracle
             assert oracle.xoshiro_below_sequence(seed, pixel, sample, bound, 256).tolist() == [(r * bound) >> 32 for r in raw], bound
 
 
-def test_shared_sincos_is_within_half_ulp_plus_epsilon(oracle):
-    """rt_sincos evaluates in double and rounds once: within 0.5000001 ulp of the true value on [0, 2*pi]."""
+def test_sincos_restatement_against_libm_and_float64(oracle):
+    """rt_sincos_libm (what the device evaluates) against the host libm the oracle calls — bit-identical on a sample (the exhaustive comparison
+    over all of [0, 2*pi] is test_libm_sincos_restatement_is_exhaustively_glibc) — and against float64: glibc's documented < 0.56 ulp."""
     rng = np.random.default_rng(1)
     phi = np.concatenate([rng.uniform(0, 2 * np.pi, 200000), [0.0, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi], np.linspace(0, 2 * np.pi, 4097)]).astype(np.float32)
     s, c = oracle.sincos(phi)
+    ls, lc = oracle.sincos(phi, libm=True)
+    assert np.array_equal(s.view(np.uint32), ls.view(np.uint32)) and np.array_equal(c.view(np.uint32), lc.view(np.uint32))
     for got, true in ((s, np.sin(phi.astype(np.float64))), (c, np.cos(phi.astype(np.float64)))):
         ulp = np.spacing(np.abs(true).astype(np.float32)).astype(np.float64)
         err = np.abs(got.astype(np.float64) - true) / np.maximum(ulp, 1e-45)
-        assert err.max() <= 0.5001, err.max()
+        assert err.max() <= 0.56, err.max()
     assert np.all(s * s + c * c < 1.0000003)
 
 
