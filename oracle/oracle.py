@@ -34,6 +34,7 @@ _PROTOS = {
     "rto_cast_rays": (C.c_int, [C.c_void_p, _abi.c_float_p, C.c_uint32, _abi.c_u32_p, _abi.c_float_p]),
     "rto_light_pdf": (C.c_int, [C.c_void_p, _abi.c_float_p, C.c_uint32, _abi.c_float_p]),
     "rto_bg_at": (C.c_int, [C.c_void_p, _abi.c_float_p, C.c_uint32, _abi.c_float_p]),
+    "rto_bg_uv": (None, [_abi.c_float_p, C.c_uint32, C.c_int, _abi.c_float_p]),
     "rto_bvh_info": (C.c_int, [C.c_void_p, C.c_int, _abi.c_u32_p, _abi.c_u32_p, _abi.c_u32_p, _abi.c_u32_p, _abi.c_u32_p]),
     "rto_tonemap_rgb8": (None, [_abi.c_float_p, C.c_size_t, _abi.c_u8_p]),
     "rto_last_error": (C.c_char_p, []),
@@ -149,6 +150,15 @@ def minstd_sequence(seed, n):
 def minstd_below_sequence(seed, bound, n):
     out = np.zeros(n, dtype=np.uint32)
     lib().rto_minstd_below_sequence(seed, bound, n, _abi.u32ptr(out))
+    return out
+
+
+def bg_uv(dirs, restated):
+    """Scene::bg_at's texture coordinates for directions (n, 3): through libm as the oracle's render loop computes them, or through the
+    restatement the device evaluates (include/rt_devspec.h rt_bg_uv)."""
+    dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((dirs.shape[0], 2), dtype=np.float32)
+    lib().rto_bg_uv(_abi.fptr(dirs), dirs.shape[0], int(bool(restated)), _abi.fptr(out))
     return out
 
 

@@ -1014,6 +1014,22 @@ int rto_bg_at(rto_scene *s, const float *dirs, uint32_t n, float *rgb_out) {
     return RT_OK;
 }
 
+// Scene::bg_at's two coordinate lines (scene.h:85-87), either as the render loop above evaluates them (libm) or through the restatement the
+// device evaluates (rt_devspec.h rt_bg_uv): the CPU tests compare the two.
+void rto_bg_uv(const float *dirs, uint32_t n, int restated, float *uv_out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
+        if (restated) {
+            rt_bg_uv(dx, dy, dz, &uv_out[2 * i], &uv_out[2 * i + 1]);
+        } else {
+            float x = 0.5 + 0.5 * std::atan2(dz, dx) / std::numbers::pi_v<float>;
+            float y = 0.5 - std::asin(dy) / std::numbers::pi_v<float>;
+            uv_out[2 * i] = x;
+            uv_out[2 * i + 1] = y;
+        }
+    }
+}
+
 int rto_bvh_info(rto_scene *s, int which, uint32_t *n_nodes, uint32_t *n_objects, uint32_t *root, uint32_t *nodes_out,
                  uint32_t *order_out) {
     const BVH &b = which == 0 ? s->scene_bvh : s->light_bvh;

@@ -110,6 +110,23 @@ def test_loader_attaches_an_environment_map(rt, sg, tmp_path):
     assert txt.arrays()["bg_texture"] == -1
 
 
+def test_bg_uv_restatement_equals_the_libm_expression(oracle, expected):
+    """rt_bg_uv (include/rt_devspec.h: what the device evaluates, restated atan2f / asinf + the mixed float / double arithmetic of
+    scene.h:85-87) against the same two lines written with libm calls, as the oracle's render loop has them: bit-identical on the golden
+    directions, a million random unit vectors, non-unit vectors, and directions with |y| > 1 (NaN on both sides)."""
+    rng = np.random.default_rng(11)
+    d = rng.normal(size=(1_000_000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    d[:1000] *= rng.uniform(0.01, 0.9, size=(1000, 1)).astype(np.float32)  # shorter than unit length
+    d[1000:1100, 1] = rng.uniform(1.0, 1.5, size=100).astype(np.float32)  # asin of > 1
+    dirs = np.concatenate([expected["dirs"], d])
+    a, b = oracle.bg_uv(dirs, restated=True), oracle.bg_uv(dirs, restated=False)
+    same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), (int((~same).sum()), dirs[(~same).any(axis=1)][:3])
+    assert np.isnan(a[:, 1]).sum() >= 90 and 0.0 <= np.nanmin(a) and np.nanmax(a) <= 1.0
+
+
 def test_atan2f_asinf_restatement_is_exhaustively_glibc(tmp_path):
     """rt_atanf_libm / rt_asinf_libm on all 2^32 floats, rt_atan2f_libm on 2^30 pairs + the special-operand grid, against the host's
     glibc (tools/proofs/atan2f_asinf_exhaustive.c): the device's environment lookup uses the reference's std::atan2 / std::asin."""
