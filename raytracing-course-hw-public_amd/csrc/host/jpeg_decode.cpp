@@ -141,9 +141,23 @@ struct Component {
 // not -7568 — the constants below are written with their signs for that reason (they are what stb_image's decoder uses)
 constexpr int fx(double x) { return (int)(x * 4096 + 0.5); }
 
+// The IDCT's 32-bit integers with WRAPPING arithmetic: valid pictures never come near the range, but the coefficients of a corrupt file can
+// overflow the sums and products, which is undefined for plain int (found by tools/fuzz_loaders.py under UBSan). Two's-complement wrap-around
+// is what the reference's stb_image build does on this hardware, and it is defined behaviour here.
+struct wi {
+    int32_t v;
+    wi() : v(0) {}
+    wi(int x) : v(x) {}
+    friend wi operator+(wi a, wi b) { return wi((int32_t)((uint32_t)a.v + (uint32_t)b.v)); }
+    friend wi operator-(wi a, wi b) { return wi((int32_t)((uint32_t)a.v - (uint32_t)b.v)); }
+    friend wi operator*(wi a, wi b) { return wi((int32_t)((uint32_t)a.v * (uint32_t)b.v)); }
+    wi &operator+=(wi b) { return *this = *this + b; }
+    friend int operator>>(wi a, int k) { return a.v >> k; } // arithmetic shift (C++20)
+};
+
 // 1-D LL&M inverse DCT on (s0..s7), results in x0..x3 / t0..t3 as the even / odd halves
 #define RT_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                   \
-    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                          \
+    wi t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                           \
     p2 = s2;                                                                         \
     p3 = s6;                                                                         \
     p1 = (p2 + p3) * fx(0.5411961f);                                                 \
@@ -185,7 +199,7 @@ void idct_block(uint8_t *out, int stride, const int16_t d[64]) {
     int val[64];
     for (int i = 0; i < 8; ++i) {
         RT_IDCT_1D(d[i], d[8 + i], d[16 + i], d[24 + i], d[32 + i], d[40 + i], d[48 + i], d[56 + i])
-        x0 += 512, x1 += 512, x2 += 512, x3 += 512;
+        x0 += wi(512), x1 += wi(512), x2 += wi(512), x3 += wi(512);
         val[i] = (x0 + t3) >> 10;
         val[56 + i] = (x0 - t3) >> 10;
         val[8 + i] = (x1 + t2) >> 10;
@@ -200,7 +214,7 @@ void idct_block(uint8_t *out, int stride, const int16_t d[64]) {
         uint8_t *o = out + (size_t)stride * i;
         RT_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
         const int bias = 65536 + (128 << 17);
-        x0 += bias, x1 += bias, x2 += bias, x3 += bias;
+        x0 += wi(bias), x1 += wi(bias), x2 += wi(bias), x3 += wi(bias);
         o[0] = clamp8((x0 + t3) >> 17);
         o[7] = clamp8((x0 - t3) >> 17);
         o[1] = clamp8((x1 + t2) >> 17);
