@@ -361,6 +361,14 @@ WideBvh build_wide(const BinBvh &bin, const float *positions, float cost_node, f
                             bi = i;
                             bs = s;
                         }
+            if (bi < 0) { // no score compares greater (NaN or -inf boxes of non-finite geometry): any free pairing, as the device collapse does
+                for (int i = 0; i < nk && bi < 0; ++i)
+                    if (slot_of[i] < 0)
+                        bi = i;
+                for (int s = 0; s < 8 && bs < 0; ++s)
+                    if (child_in[s] < 0)
+                        bs = s;
+            }
             slot_of[bi] = bs;
             child_in[bs] = bi;
         }

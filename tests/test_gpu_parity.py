@@ -464,6 +464,15 @@ def test_errors_are_reported_not_thrown(gpu, sg):
     with pytest.raises(gpu.RtError):
         dev.run_raytracer(8, 8, 1, rng_mode=gpu.RT_RNG_REFERENCE, shard_count=2, shard_block=100)
     dev.close()
+    # non-finite vertex positions never reach a builder or a kernel (every build mode)
+    for bad in (np.nan, np.inf, -np.inf):
+        sc2 = sg.boxes_scene(n_boxes=2, seed=1)
+        sc2.positions = sc2.positions.copy()
+        sc2.positions[3, 1, 2] = bad
+        for kw in ({}, {"device_bvh": True}, {"device_bvh": True, "wide": True}, {"wide": True}):
+            with pytest.raises(gpu.RtError) as e:
+                gpu.DeviceScene(sc2, **kw)
+            assert e.value.code == 1 and "non-finite vertex position (triangle 3)" in str(e.value)  # RT_ERR_INVALID_ARG
 
 
 def test_cli_end_to_end(gpu, oracle, sg, tmp_path):

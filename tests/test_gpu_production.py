@@ -374,6 +374,45 @@ def test_wide_on_tiny_scenes(gpu, oracle, sg, n_tris):
         orc.close()
 
 
+@pytest.mark.parametrize("scale_log2", [36, 20, -8])
+def test_production_build_at_extreme_scales(gpu, oracle, sg, scale_log2):
+    """The same room scaled by 2^36, 2^20 and 2^-8: every production build against the oracle — the superset contract on 12 000 rays, every
+    wide box containing its contents in exact arithmetic, the render. 2^36 is the top of the range in which the reference's own arithmetic
+    is sound for a scene of this size: from about 2^40 its triangle test's triple products overflow and it reports "hits" at t = inf
+    (measured: 11 853 of 12 000 rays at 2^41). The parity kernels reproduce those (test_render_outside_fast_division_range); the production
+    traversal culls against the best distance so far and reports a miss instead. Below 2^-8 the scene is smaller than the reference's
+    minimum hit distance EPS and nothing is hit at all."""
+    sc = sg.room_scene(400, seed=77, n_lights=3, n_materials=5, tex_size=0)
+    k = np.float32(2.0) ** np.float32(scale_log2)
+    sc.positions = (sc.positions * k).astype(np.float32)
+    sc.camera.position = (np.asarray(sc.camera.position, dtype=np.float32) * k).astype(np.float32)
+    assert np.isfinite(sc.positions).all()
+    orc = oracle.OracleScene(sc)
+    rays = random_rays(sc, 12000, seed=5)
+    op, ob = orc.cast_rays(rays)
+    assert (op != 0xFFFFFFFF).sum() > 8000 and np.isfinite(ob[op != 0xFFFFFFFF, 2]).all()
+    ofb, _ = orc.run_raytracer(32, 24, 3, seed=3)
+    try:
+        for kw in (dict(wide=True), dict(wide=True, device_bvh=True), dict(device_bvh=True)):
+            dev = gpu.DeviceScene(sc, **kw)
+            try:
+                gp, gb, _ = dev.cast_rays_ex(rays, gpu.RT_CAST_EXTEND)
+                ties, closer = compare_superset_hits_with_oracle(op, ob, gp, gb, f"scale 2^{scale_log2} {kw}")
+                assert ties + closer <= 12, (scale_log2, kw, ties, closer)
+                if kw.get("wide"):
+                    dump = dev.bvh_wide_dump()
+                    from test_wide_build import walk_and_check
+
+                    walk_and_check(dump["nodes"], dump["tris"][:, 9].copy(), sc.positions)
+                gfb, _ = dev.run_raytracer(32, 24, 3, seed=3)
+                differing = int((gfb.view(np.uint32) != ofb.view(np.uint32)).any(axis=2).sum())
+                assert differing <= 8, (scale_log2, kw, differing)
+            finally:
+                dev.close()
+    finally:
+        orc.close()
+
+
 def test_wide_with_analytic_primitives(gpu, oracle, tmp_path):
     """Scene-txt scenes (BASELINE configs 1-2) through the production build: BOX / TRIANGLE primitives in the wide tree, ELLIPSOID /
     PLANE through wf_extend_prims after it; the oracle's image within 1e-5."""

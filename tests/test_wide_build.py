@@ -148,3 +148,20 @@ def test_wide_tree_slots_follow_the_octants(rt, sg):
             agree += int(((c - mid) * sign > 0).sum())
             total += 3
     assert agree / total > 0.7, agree / total
+
+
+def test_non_finite_geometry_is_memory_safe(rt):
+    """NaN / infinite / extreme coordinates through both host builders: no crash (tools/sanitize_cpu.sh runs this under AddressSanitizer: the
+    wide builder's slot assignment once indexed with -1 when every score was NaN), a tree over all triangles comes back. rt_create itself
+    refuses non-finite positions (tests/test_gpu_parity.py), these entry points take raw arrays."""
+    rng = np.random.default_rng(1)
+    for trial in range(12):
+        n = int(rng.integers(40, 1500))
+        pos = rng.uniform(-1, 1, size=(n, 9)).astype(np.float32)
+        k = int(rng.integers(1, max(2, n // 3)))
+        idx, col = rng.integers(0, n, size=k), rng.integers(0, 9, size=k)
+        pos[idx, col] = [np.nan, np.inf, -np.inf, 3.0e38, -3.0e38, 1e-45][trial % 6]
+        b = rt.bvh_build_host(pos)
+        w = rt.bvh_wide_build_host(pos)
+        assert sorted(w["order"].tolist()) == list(range(n)) and len(w["nodes"]) >= 1
+        assert sorted(b["order"].tolist()) == list(range(n))
