@@ -67,11 +67,20 @@ struct Builder { // one per worker thread: own node list and scratch, shared Bui
     std::vector<HostNode> nodes;
     std::vector<float> pref, suf;
     std::vector<Keyed> scratch;
+    std::vector<Box> sorted_box; // the boxes of the slice being split, in sorted order: ONE gather through objs[] per split, then
+                                 // the two sweeps and the children's bounds read memory in order (the gathers were the build's bottleneck)
 
     Box bounds_of(const uint32_t *objs, size_t n) const { // bvh.h:315-321
         Box r;
         for (size_t i = 0; i < n; ++i)
             r.extend(tri_box[objs[i]]);
+        return r;
+    }
+    // bounds_of(objs + first, n) right after split() sorted the slice: the same boxes in the same order, read from sorted_box
+    Box bounds_of_sorted(size_t first, size_t n) const {
+        Box r;
+        for (size_t i = 0; i < n; ++i)
+            r.extend(sorted_box[first + i]);
         return r;
     }
 
@@ -83,21 +92,24 @@ struct Builder { // one per worker thread: own node list and scratch, shared Bui
         for (size_t i = 0; i < n; ++i)
             scratch[i] = {keys[objs[i]], objs[i]};
         std::sort(scratch.begin(), scratch.end(), [](const Keyed &l, const Keyed &r) { return l.key < r.key; });
-        for (size_t i = 0; i < n; ++i)
+        sorted_box.resize(n);
+        for (size_t i = 0; i < n; ++i) {
             objs[i] = scratch[i].idx;
+            sorted_box[i] = tri_box[objs[i]];
+        }
 
         pref.clear();
         suf.clear();
         Box acc;
         pref.push_back(acc.surface_area());
         for (size_t i = 0; i < n; ++i) {
-            acc.extend(tri_box[objs[i]]);
+            acc.extend(sorted_box[i]);
             pref.push_back(acc.surface_area());
         }
         acc = Box();
         suf.push_back(acc.surface_area());
         for (size_t i = n; i-- > 0;) {
-            acc.extend(tri_box[objs[i]]);
+            acc.extend(sorted_box[i]);
             suf.push_back(acc.surface_area());
         }
         size_t best = n; // objs.end(): "no split"
@@ -136,8 +148,9 @@ struct Builder { // one per worker thread: own node list and scratch, shared Bui
         nd.left = nd.right = RT_NONE;
         nd.obj_begin = nd.obj_end = 0;
         nodes.push_back(nd);
-        uint32_t l = build(offset, objs, nl, bounds_of(objs, nl), min_node_size, depth_left - 1);
-        uint32_t r = build((uint32_t)(offset + nl), objs + nl, nr, bounds_of(objs + nl, nr), min_node_size, depth_left - 1);
+        const Box lb = bounds_of_sorted(0, nl), rb = bounds_of_sorted(nl, nr); // before the recursion reuses sorted_box
+        uint32_t l = build(offset, objs, nl, lb, min_node_size, depth_left - 1);
+        uint32_t r = build((uint32_t)(offset + nl), objs + nl, nr, rb, min_node_size, depth_left - 1);
         nodes[idx].left = l;
         nodes[idx].right = r;
         return idx;
@@ -170,7 +183,13 @@ static std::vector<HostNode> build_parallel(const BuildData &data, uint32_t offs
     if (depth_left == 0 || nl == 0 || nr == 0 || (nl < 4 && nr < 4)) // leaf rules of bvh.h:336-346
         return {nd};
     nd.obj_begin = nd.obj_end = 0;
-    const Box lb = w.bounds_of(objs, nl), rb = w.bounds_of(objs + nl, nr);
+    const Box lb = w.bounds_of_sorted(0, nl), rb = w.bounds_of_sorted(nl, nr);
+    { // this task only waits from here on: give its scratch back before the children allocate theirs
+        std::vector<Keyed>().swap(w.scratch);
+        std::vector<Box>().swap(w.sorted_box);
+        std::vector<float>().swap(w.pref);
+        std::vector<float>().swap(w.suf);
+    }
     auto left_task = std::async(std::launch::async, build_parallel, std::cref(data), offset, objs, nl, lb, depth_left - 1, par_levels - 1);
     std::vector<HostNode> right = build_parallel(data, (uint32_t)(offset + nl), objs + nl, nr, rb, depth_left - 1, par_levels - 1);
     std::vector<HostNode> left = left_task.get();
@@ -218,9 +237,10 @@ HostBvh build_bvh(const float *positions, uint32_t n_total, const std::vector<ui
     Builder b(data);
     Box root_box = b.bounds_of(out.order.data(), out.order.size());
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    int par_levels = 0;
-    while ((1u << par_levels) < hw && par_levels < 6)
-        ++par_levels;
+    // Surface-area splits are far from balanced (a 10 : 90 cut is common), so a fixed number of parallel levels leaves most threads waiting
+    // for the largest subtree. Every subtree of at least 65 536 triangles becomes a task instead (build_parallel's size test), however deep it
+    // sits: a few hundred short-lived threads for 10^7 triangles, all cores busy until the end. One hardware thread: plain recursion.
+    const int par_levels = hw > 1 ? 64 : 0;
     out.nodes = build_parallel(data, 0, out.order.data(), out.order.size(), root_box, 64, par_levels);
     out.root = 0;
     return out;
