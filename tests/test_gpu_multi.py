@@ -75,6 +75,39 @@ def test_replicated_render_over_rehearsal_transport(gpu, scene, single, monkeypa
         grp.close()
 
 
+def test_group_with_production_build_and_environment_map(gpu, sg, oracle, monkeypatch):
+    """Three replicas of a scene with an environment map, each building the production tree on its device (PLOC + wide collapse): the gathered image
+    equals one replica's, and the parity-build group equals the ORACLE (the host half of rt_create, incl. the map's texture view, is shared)."""
+    import os
+
+    monkeypatch.setenv("RT_GROUP_TRANSPORT", "copy")
+    sc = sg.room_scene(700, seed=52, n_lights=0, n_materials=5, tex_size=8, n_tex_sets=2, open_room=True)
+    env = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "envmap", "env.png")
+    sc.textures = list(sc.textures) + [gpu.image_decode(env)]
+    sc.bg_texture = len(sc.textures) - 1
+    orc = oracle.OracleScene(sc)
+    ofb, _ = orc.run_raytracer(W, H, SPP, seed=4)
+    orc.close()
+    grp = gpu.DeviceScene(sc, device=[0, 0, 0])
+    got, _ = grp.run_raytracer(W, H, SPP, seed=4, shard_block=256)
+    assert np.array_equal(got.view(np.uint32), ofb.view(np.uint32))
+    d = np.random.default_rng(8).normal(size=(300, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    one = gpu.DeviceScene(sc)
+    assert np.array_equal(grp.bg_at(d).view(np.uint32), one.bg_at(d).view(np.uint32))  # the probe is served by the first replica
+    one.close()
+    grp.close()
+    one = gpu.DeviceScene(sc, device_bvh=True, wide=True)
+    grp = gpu.DeviceScene(sc, device=[0, 0, 0], device_bvh=True, wide=True)
+    want, _ = one.run_raytracer(W, H, SPP, seed=4)
+    got, _ = grp.run_raytracer(W, H, SPP, seed=4, shard_block=256)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))  # every replica builds the same tree from the same arrays
+    differing = int((got.view(np.uint32) != ofb.view(np.uint32)).any(axis=2).sum())
+    assert differing <= 0.01 * W * H, differing  # production contract against the oracle (ties / the reference's pruning quirk only)
+    one.close()
+    grp.close()
+
+
 def test_rccl_refusal_is_reported_as_comm_error(gpu, scene, monkeypatch):
     """The same GPU twice in one communicator: ncclCommInitAll refuses -> RT_ERR_COMM with RCCL's message, no crash,
     no half-built scene left behind."""
