@@ -33,6 +33,10 @@ int rt_loaded_info(const rt_loaded_scene *s, uint32_t *width, uint32_t *height, 
  * picture (PNG / JPEG / Radiance HDR, as rt_image_decode_file), appends it to the scene's textures and points desc.bg_texture at it.
  * The reference fixes path and intensity at compile time ("env.hdr", 1); the CLI takes them from RT_ENV_MAP / RT_ENV_MAP_INTENSITY. */
 int rt_loaded_set_env_map(rt_loaded_scene *s, const char *image_path, float intensity);
+/* scene.h:479-498 with ADD_LIGHT_TRIANGLE = true (config.h:40-47): appends an emissive triangle given in the camera's frame (rel: 3 x (right, up,
+ * forward) coordinates; the reference's constants are {10, 0, -0.1}, {0, 10, -0.1}, {0, -10, -0.1} and intensity 10) with a default material.
+ * The CLI takes it from RT_LIGHT_TRIANGLE=1 (+ RT_LIGHT_TRIANGLE_INTENSITY). */
+int rt_loaded_add_light_triangle(rt_loaded_scene *s, const float rel[9], float intensity);
 const rt_scene_desc *rt_loaded_desc(const rt_loaded_scene *s);
 void rt_loaded_free(rt_loaded_scene *s);
 

@@ -11,6 +11,10 @@
 //   ref_probe bgat     <gltf> <W> <H> <image> <dirs.bin> <out.bin>  Scene::bg_at (scene.h:83-89) with scene.bg = load_img(image) as main.cpp:29-31
 //                                                          does under USE_ENV_MAP, for explicit directions (3 floats each) -> rgb
 //   ref_probe envrender <gltf> <W> <H> <image> <spp> <out.ppm>  main.cpp:27-43 with the environment map loaded: the reference's own render
+//   ref_probe lighttri <gltf> <W> <H> <out.bin>            the extra light source of scene.h:479-498 (compile-time off: ADD_LIGHT_TRIANGLE), put
+//                                                          together here from the reference's own constants and helpers (config.h:41-47,
+//                                                          geometry::transform3, triangle::normal): 9 positions, 3 normal floats, intensity
+//   ref_probe lightrender <gltf> <W> <H> <spp> <out.ppm>   ... that object appended to scene.objects, then run_raytracer + Image::write
 //   ref_probe sphere   <radius> 0 0 <rays.bin> <out.bin>   intersect_ray_sphere (raytracer.h:61-77, unused by the reference's render loop; the
 //                                                          scene-txt ELLIPSOID restates it): (t1, t2) per ray
 //   ref_probe texture  <image> 0 0 <out.bin>               geometry::Texture::load_img (the reference's stb_image build, 4 channels
@@ -112,6 +116,44 @@ int main(int argc, char **argv) {
             put_f32(o, c.b());
         }
         write_words(argv[7], o);
+        return 0;
+    }
+    if (mode == "lighttri" || mode == "lightrender") {
+        std::vector<uint32_t> o;
+        geometry::triangle tr = *reinterpret_cast<const geometry::triangle *>(&LIGHT_TRIANGLE_RELATIVE_POS);
+        tr.a() = scene.camera.position + geometry::transform3(tr.a(), scene.camera.right, scene.camera.up, scene.camera.forward);
+        tr.b() = scene.camera.position + geometry::transform3(tr.b(), scene.camera.right, scene.camera.up, scene.camera.forward);
+        tr.c() = scene.camera.position + geometry::transform3(tr.c(), scene.camera.right, scene.camera.up, scene.camera.forward);
+        if (mode == "lightrender") { // ... appended to the scene as scene.h:480-497 does, then the reference's own render loop
+            if (argc < 7)
+                return 2;
+            scene.objects.emplace_back();
+            geometry::Object &ls = scene.objects.back();
+            ls.shape = tr;
+            ls.material.emission = {LIGHT_TRIANGLE_INTENSITY, LIGHT_TRIANGLE_INTENSITY, LIGHT_TRIANGLE_INTENSITY};
+            std::fill(ls.attrs.normals.begin(), ls.attrs.normals.end(), tr.normal());
+            std::fill(ls.attrs.tex_coords.begin(), ls.attrs.tex_coords.end(), geometry::vec2(0, 0));
+            std::fill(ls.attrs.tangents.begin(), ls.attrs.tangents.end(), geometry::vec3(1, 0, 0));
+            scene.samples = std::strtol(argv[5], nullptr, 10);
+            Image img(width, height, scene.bg_color);
+            run_raytracer(scene, img);
+            std::ofstream out(argv[6], std::ios::binary);
+            img.write(out);
+            return 0;
+        }
+        for (auto *v : {&tr.a(), &tr.b(), &tr.c()})
+            for (float c : v->val)
+                put_f32(o, c);
+        for (float c : tr.normal().val)
+            put_f32(o, c);
+        put_f32(o, LIGHT_TRIANGLE_INTENSITY);
+        geometry::material dflt;
+        for (float c : dflt.color.val)
+            put_f32(o, c);
+        put_f32(o, dflt.roughness);
+        put_f32(o, dflt.metallic);
+        put_f32(o, dflt.ior);
+        write_words(argv[5], o);
         return 0;
     }
     RaytracerStaticContext ctx(scene);

@@ -100,6 +100,13 @@ class LoadedScene:
         """main.cpp:28-31 under USE_ENV_MAP: scene.bg = Texture::load_img(image_path), bg_color = intensity (rt_loaded_set_env_map)."""
         _check(lib().rt_loaded_set_env_map(self._h, os.fsencode(image_path), C.c_float(intensity)))
 
+    LIGHT_TRIANGLE_RELATIVE_POS = ((10.0, 0.0, -0.1), (0.0, 10.0, -0.1), (0.0, -10.0, -0.1))  # config.h:43-47
+
+    def add_light_triangle(self, rel=LIGHT_TRIANGLE_RELATIVE_POS, intensity: float = 10.0) -> None:
+        """scene.h:479-498 under ADD_LIGHT_TRIANGLE: an emissive triangle in the camera's frame (rt_loaded_add_light_triangle)."""
+        r = np.ascontiguousarray(rel, dtype=np.float32).reshape(9)
+        _check(lib().rt_loaded_add_light_triangle(self._h, fptr(r), C.c_float(intensity)))
+
     def close(self) -> None:
         if self._h:
             lib().rt_loaded_free(self._h)

@@ -455,5 +455,49 @@ extern "C" int rt_loaded_set_env_map(rt_loaded_scene *s, const char *image_path,
     return RT_OK;
 }
 
+// scene.h:479-498 for ADD_LIGHT_TRIANGLE = true (config.h:41-47): one more object, an emissive triangle given in the camera's frame
+// (vertex = position + r.x * right + r.y * up + r.z * forward), geometric normal, zero texture coordinates, tangent (1, 0, 0), a default
+// material (geometry.h:604-613) whose emission is the intensity. The reference fixes position and intensity at compile time.
+extern "C" int rt_loaded_add_light_triangle(rt_loaded_scene *s, const float rel[9], float intensity) {
+    if (!s || !rel)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_loaded_add_light_triangle: null argument");
+    const rt_camera &cam = s->desc.camera;
+    V3 p[3];
+    for (int k = 0; k < 3; ++k) { // w + transform3(r, x, y, z), geometry.h:355-359: r.x * x + r.y * y + r.z * z, then the sum with w
+        const float rx = rel[3 * k], ry = rel[3 * k + 1], rz = rel[3 * k + 2];
+        float t[3];
+        for (int c = 0; c < 3; ++c)
+            t[c] = cam.position[c] + ((rx * cam.right[c] + ry * cam.up[c]) + rz * cam.forward[c]);
+        p[k] = {t[0], t[1], t[2]};
+    }
+    const V3 v{p[1].x - p[0].x, p[1].y - p[0].y, p[1].z - p[0].z}, u{p[2].x - p[0].x, p[2].y - p[0].y, p[2].z - p[0].z};
+    const V3 n = norm3({v.y * u.z - v.z * u.y, v.z * u.x - v.x * u.z, v.x * u.y - v.y * u.x}); // triangle::normal geometry.h:477-479
+    for (int k = 0; k < 3; ++k) {
+        s->positions.insert(s->positions.end(), {p[k].x, p[k].y, p[k].z});
+        s->normals.insert(s->normals.end(), {n.x, n.y, n.z});
+        s->texcoords.insert(s->texcoords.end(), {0.0f, 0.0f});
+        s->tangents.insert(s->tangents.end(), {1.0f, 0.0f, 0.0f});
+    }
+    rt_material_desc m{};
+    m.color[0] = m.color[1] = m.color[2] = m.color[3] = 1.0f;
+    m.emission[0] = m.emission[1] = m.emission[2] = intensity;
+    m.roughness = 1.0f;
+    m.metallic = 1.0f;
+    m.ior = 1.5f;
+    m.color_tex = m.emissive_tex = m.metallic_roughness_tex = m.normal_tex = RT_TEX_NONE;
+    s->materials.push_back(m);
+    s->material_ids.push_back((uint32_t)s->materials.size() - 1u);
+    rt_scene_desc &d = s->desc; // the vectors may have moved
+    d.n_triangles = (uint32_t)s->material_ids.size();
+    d.positions = s->positions.data();
+    d.normals = s->normals.data();
+    d.texcoords = s->texcoords.data();
+    d.tangents = s->tangents.data();
+    d.material_ids = s->material_ids.data();
+    d.n_materials = (uint32_t)s->materials.size();
+    d.materials = s->materials.data();
+    return RT_OK;
+}
+
 extern "C" const rt_scene_desc *rt_loaded_desc(const rt_loaded_scene *s) { return s ? &s->desc : nullptr; }
 extern "C" void rt_loaded_free(rt_loaded_scene *s) { delete s; }

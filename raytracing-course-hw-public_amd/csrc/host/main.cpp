@@ -4,7 +4,8 @@
 // rt_create + rt_render_rgb8 through the C ABI (include/rt_abi.h): render and film (image.h) on the device.
 // Optional environment: RT_DEVICE (HIP ordinal; unset = every visible GPU: replicas + RCCL gather inside the library, the
 // node-scale counterpart of the thread pool of raytracer.h:636-665), RT_RNG_MODE (device|reference), RT_SEED,
-// RT_ENV_MAP (+ RT_ENV_MAP_INTENSITY): the environment map the reference enables at compile time (config.h:36-38, main.cpp:28-31).
+// RT_ENV_MAP (+ RT_ENV_MAP_INTENSITY): the environment map the reference enables at compile time (config.h:36-38, main.cpp:28-31);
+// RT_LIGHT_TRIANGLE=1 (+ RT_LIGHT_TRIANGLE_INTENSITY): its extra light source in camera coordinates (config.h:40-47, scene.h:479-498).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +42,14 @@ int main(int argc, char **argv) {
         if (rt_loaded_set_env_map(loaded, env_map, k ? std::strtof(k, nullptr) : 1.0f) != RT_OK) {
             rt_loaded_free(loaded);
             return die("environment map");
+        }
+    }
+    if (const char *lt = std::getenv("RT_LIGHT_TRIANGLE"); lt && std::atoi(lt) != 0) { // ADD_LIGHT_TRIANGLE / LIGHT_TRIANGLE_* of config.h:40-47
+        const float rel[9] = {10, 0, -0.1f, 0, 10, -0.1f, 0, -10, -0.1f};
+        const char *k = std::getenv("RT_LIGHT_TRIANGLE_INTENSITY");
+        if (rt_loaded_add_light_triangle(loaded, rel, k ? std::strtof(k, nullptr) : 10.0f) != RT_OK) {
+            rt_loaded_free(loaded);
+            return die("light triangle");
         }
     }
     const char *dev_env = std::getenv("RT_DEVICE");

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Golden vectors for the extra light source the reference can add in camera coordinates (ADD_LIGHT_TRIANGLE, config.h:40-47; scene.h:479-498),
+container only. The option is compile-time off, so oracle/_ref/ref_probe — which includes the reference's headers — puts the object together from
+the reference's own constants and helpers (LIGHT_TRIANGLE_RELATIVE_POS / _INTENSITY, geometry::transform3, triangle::normal, the default
+geometry::material) the way scene.h:480-497 does, dumps it, and renders the scene with it through the reference's run_raytracer.
+Writes tests/golden/light_triangle/: expected.npz and two PPMs.    python tests/golden/make_light_triangle_golden.py
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import importlib  # noqa: E402
+
+import oracle  # noqa: E402
+from conftest import golden_scene_specs, make_scene  # noqa: E402
+
+rt = importlib.import_module("raytracing-course-hw-public_amd")
+OUT = os.path.join(HERE, "light_triangle")
+W, H, SPP = 64, 48, 4
+
+
+def main():
+    assert oracle.have_reference_build()
+    os.makedirs(OUT, exist_ok=True)
+    exp = {}
+    with tempfile.TemporaryDirectory() as td:
+        cases = {"features": os.path.join(HERE, "features", "features.gltf")}
+        for name in ("open_nolight", "room_plain"):
+            cases[name] = rt.scenegen.write_gltf(make_scene(rt.scenegen, golden_scene_specs()[name]), os.path.join(td, name + ".gltf"))
+        for name, gltf in cases.items():
+            oracle.ref_probe("lighttri", gltf, W, H, os.path.join(td, "lt.bin"))
+            exp[name] = np.fromfile(os.path.join(td, "lt.bin"), dtype=np.float32)
+        for name in ("open_nolight", "features"):
+            oracle.ref_probe("lightrender", cases[name], W, H, SPP, os.path.join(OUT, f"{name}_light_{W}x{H}x{SPP}.ppm"))
+    np.savez_compressed(os.path.join(OUT, "expected.npz"), **exp)
+    print({k: v.tolist()[:12] for k, v in exp.items()})
+
+
+if __name__ == "__main__":
+    main()
