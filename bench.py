@@ -72,7 +72,7 @@ PROFILE_ROUND = "r03"
 CONFIG4_SPP = 1000
 
 WORKLOADS = {
-    "sponza": dict(label="S-sponza", width=1000, height=1000, spp_per_gpu=64, triangles=262144, offset=0.15, tex_size=1024, cpu_share=16,
+    "sponza": dict(label="S-sponza", width=1000, height=1000, spp_per_gpu=64, triangles=262144, offset=0.15, tex_size=1024, cpu_share=4,
                    metric="Msamples/sec (whole node) on Sponza 1000x1000"),
     "s10m": dict(label="S-10M", width=2048, height=2048, spp_per_gpu=32, triangles=10_000_000, offset=0.03, tex_size=1024, cpu_share=256,
                  metric="Msamples/sec (whole node) on synthetic 10M-triangle scene 2048x2048"),
