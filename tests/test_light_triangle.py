@@ -72,3 +72,24 @@ def test_device_render_with_light_triangle_equals_the_reference_bytes(gpu, sg, o
     assert np.array_equal(gfb.view(np.uint32), ofb.view(np.uint32)) and gst["light_tri_tests"] == ost["light_tri_tests"]
     dev.close()
     orc.close()
+
+
+@pytest.mark.gpu
+def test_cli_switches_reproduce_the_reference_renders(gpu, sg, tmp_path):
+    """run.sh with RT_LIGHT_TRIANGLE=1 / RT_ENV_MAP=<picture> in reference-RNG mode writes the PPM the reference's own render loop produced with the
+    corresponding compile-time switch on (ref_probe lightrender / envrender): the whole host flow (loader, switch, device render, device film, writer)."""
+    import subprocess
+
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, RT_RNG_MODE="reference", RT_DEVICE="0")
+    out = tmp_path / "light.ppm"
+    subprocess.check_call([os.path.join(root, "run.sh"), os.path.join(HERE, "golden", "features", "features.gltf"), str(W), str(H), str(SPP), str(out)],
+                          env=dict(env, RT_LIGHT_TRIANGLE="1"))
+    assert out.read_bytes() == open(os.path.join(GOLD, f"features_light_{W}x{H}x{SPP}.ppm"), "rb").read()
+    path = sg.write_gltf(make_scene(sg, golden_scene_specs()["open_nolight"]), str(tmp_path / "open.gltf"))
+    envdir = os.path.join(HERE, "golden", "envmap")
+    out2 = tmp_path / "env.ppm"
+    subprocess.check_call([os.path.join(root, "run.sh"), path, str(W), str(H), str(SPP), str(out2)], env=dict(env, RT_ENV_MAP=os.path.join(envdir, "env.png")))
+    assert out2.read_bytes() == open(os.path.join(envdir, f"open_nolight_envpng_{W}x{H}x{SPP}.ppm"), "rb").read()
+    r = subprocess.run([os.path.join(root, "run.sh"), path, str(W), str(H), "1", str(out2)], env=dict(env, RT_ENV_MAP=str(tmp_path / "missing.hdr")), capture_output=True, text=True)
+    assert r.returncode == 1 and "environment map" in r.stderr
