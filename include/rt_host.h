@@ -37,6 +37,9 @@ int rt_loaded_set_env_map(rt_loaded_scene *s, const char *image_path, float inte
  * forward) coordinates; the reference's constants are {10, 0, -0.1}, {0, 10, -0.1}, {0, -10, -0.1} and intensity 10) with a default material.
  * The CLI takes it from RT_LIGHT_TRIANGLE=1 (+ RT_LIGHT_TRIANGLE_INTENSITY). */
 int rt_loaded_add_light_triangle(rt_loaded_scene *s, const float rel[9], float intensity);
+/* USE_TEXTURES = false (config.h:31-32): every Texture::sample returns the texture's first texel (geometry.h:547-574), which is what a 1x1 texture
+ * does: the textures are cut down to their first texel. CLI: RT_USE_TEXTURES=0. */
+int rt_loaded_disable_textures(rt_loaded_scene *s);
 const rt_scene_desc *rt_loaded_desc(const rt_loaded_scene *s);
 void rt_loaded_free(rt_loaded_scene *s);
 

@@ -15,6 +15,9 @@
 //                                                          together here from the reference's own constants and helpers (config.h:41-47,
 //                                                          geometry::transform3, triangle::normal): 9 positions, 3 normal floats, intensity
 //   ref_probe lightrender <gltf> <W> <H> <spp> <out.ppm>   ... that object appended to scene.objects, then run_raytracer + Image::write
+//   ref_probe notexrender <gltf> <W> <H> <spp> <out.ppm>   USE_TEXTURES = false (config.h:31-32; compile-time on): Texture::sample then returns data[0],
+//                                                          which is its answer for a one-texel texture: every loaded texture is cut down to its first
+//                                                          texel (the Texture objects stay where the materials point), then run_raytracer + Image::write
 //   ref_probe sphere   <radius> 0 0 <rays.bin> <out.bin>   intersect_ray_sphere (raytracer.h:61-77, unused by the reference's render loop; the
 //                                                          scene-txt ELLIPSOID restates it): (t1, t2) per ray
 //   ref_probe texture  <image> 0 0 <out.bin>               geometry::Texture::load_img (the reference's stb_image build, 4 channels
@@ -116,6 +119,20 @@ int main(int argc, char **argv) {
             put_f32(o, c.b());
         }
         write_words(argv[7], o);
+        return 0;
+    }
+    if (mode == "notexrender") {
+        if (argc < 7)
+            return 2;
+        for (auto &t : scene.textures) {
+            t.data.resize(1);
+            t.width = t.height = 1;
+        }
+        scene.samples = std::strtol(argv[5], nullptr, 10);
+        Image img(width, height, scene.bg_color);
+        run_raytracer(scene, img);
+        std::ofstream out(argv[6], std::ios::binary);
+        img.write(out);
         return 0;
     }
     if (mode == "lighttri" || mode == "lightrender") {

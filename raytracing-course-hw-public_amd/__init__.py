@@ -100,6 +100,10 @@ class LoadedScene:
         """main.cpp:28-31 under USE_ENV_MAP: scene.bg = Texture::load_img(image_path), bg_color = intensity (rt_loaded_set_env_map)."""
         _check(lib().rt_loaded_set_env_map(self._h, os.fsencode(image_path), C.c_float(intensity)))
 
+    def disable_textures(self) -> None:
+        """USE_TEXTURES = false (config.h:31-32): every texture lookup returns the texture's first texel (rt_loaded_disable_textures)."""
+        _check(lib().rt_loaded_disable_textures(self._h))
+
     LIGHT_TRIANGLE_RELATIVE_POS = ((10.0, 0.0, -0.1), (0.0, 10.0, -0.1), (0.0, -10.0, -0.1))  # config.h:43-47
 
     def add_light_triangle(self, rel=LIGHT_TRIANGLE_RELATIVE_POS, intensity: float = 10.0) -> None:

@@ -174,6 +174,7 @@ HOST_PROTOTYPES = {
     "rt_loaded_desc": (C.POINTER(RtSceneDesc), [C.c_void_p]),
     "rt_loaded_set_env_map": (C.c_int, [C.c_void_p, C.c_char_p, C.c_float]),
     "rt_loaded_add_light_triangle": (C.c_int, [C.c_void_p, c_float_p, C.c_float]),
+    "rt_loaded_disable_textures": (C.c_int, [C.c_void_p]),
     "rt_hdr_decode_file": (C.c_int, [C.c_char_p, c_u32_p, c_u32_p, C.POINTER(c_u8_p)]),
     "rt_loaded_free": (None, [C.c_void_p]),
     "rt_write_ppm": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, c_u8_p]),

@@ -455,6 +455,16 @@ extern "C" int rt_loaded_set_env_map(rt_loaded_scene *s, const char *image_path,
     return RT_OK;
 }
 
+// USE_TEXTURES = false (config.h:31-32, geometry.h:547-574): Texture::sample returns the texture's FIRST texel, unfiltered and without gamma,
+// whatever the coordinates. That is exactly what it does for a 1x1 texture, so every texture is cut down to its first texel.
+extern "C" int rt_loaded_disable_textures(rt_loaded_scene *s) {
+    if (!s)
+        return rt::fail(RT_ERR_INVALID_ARG, "rt_loaded_disable_textures: null argument");
+    for (rt_texture_desc &t : s->textures)
+        t.width = t.height = 1; // rgba8 keeps pointing at the picture: its first four bytes are texel 0
+    return RT_OK;
+}
+
 // scene.h:479-498 for ADD_LIGHT_TRIANGLE = true (config.h:41-47): one more object, an emissive triangle given in the camera's frame
 // (vertex = position + r.x * right + r.y * up + r.z * forward), geometric normal, zero texture coordinates, tangent (1, 0, 0), a default
 // material (geometry.h:604-613) whose emission is the intensity. The reference fixes position and intensity at compile time.

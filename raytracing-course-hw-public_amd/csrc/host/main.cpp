@@ -44,6 +44,8 @@ int main(int argc, char **argv) {
             return die("environment map");
         }
     }
+    if (const char *ut = std::getenv("RT_USE_TEXTURES"); ut && std::atoi(ut) == 0) // USE_TEXTURES = false, config.h:31-32
+        rt_loaded_disable_textures(loaded);
     if (const char *lt = std::getenv("RT_LIGHT_TRIANGLE"); lt && std::atoi(lt) != 0) { // ADD_LIGHT_TRIANGLE / LIGHT_TRIANGLE_* of config.h:40-47
         const float rel[9] = {10, 0, -0.1f, 0, 10, -0.1f, 0, -10, -0.1f};
         const char *k = std::getenv("RT_LIGHT_TRIANGLE_INTENSITY");

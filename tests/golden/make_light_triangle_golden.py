@@ -39,6 +39,10 @@ def main():
             exp[name] = np.fromfile(os.path.join(td, "lt.bin"), dtype=np.float32)
         for name in ("open_nolight", "features"):
             oracle.ref_probe("lightrender", cases[name], W, H, SPP, os.path.join(OUT, f"{name}_light_{W}x{H}x{SPP}.ppm"))
+        # USE_TEXTURES = false (config.h:31-32): the reference's render with every texture cut down to its first texel
+        cases["room_textured"] = rt.scenegen.write_gltf(make_scene(rt.scenegen, golden_scene_specs()["room_textured"]), os.path.join(td, "room_textured.gltf"))
+        for name in ("room_textured", "features"):
+            oracle.ref_probe("notexrender", cases[name], W, H, SPP, os.path.join(OUT, f"{name}_notex_{W}x{H}x{SPP}.ppm"))
     np.savez_compressed(os.path.join(OUT, "expected.npz"), **exp)
     print({k: v.tolist()[:12] for k, v in exp.items()})
 

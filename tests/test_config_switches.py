@@ -1,6 +1,7 @@
-"""The reference's optional extra light source in camera coordinates (ADD_LIGHT_TRIANGLE, config.h:40-47; scene.h:479-498; compile-time off):
-rt_loaded_add_light_triangle against what the reference's own constants and helpers produce (tests/golden/light_triangle, made by ref_probe),
-and the oracle's render of the scene with it against the reference's render."""
+"""The reference's compile-time switches (config.h:30-47) as run-time options of the host loader, each pinned to the reference: the extra light source in
+camera coordinates (ADD_LIGHT_TRIANGLE, scene.h:479-498; rt_loaded_add_light_triangle) against what the reference's own constants and helpers produce and
+against its render loop's output (tests/golden/light_triangle, made by ref_probe), USE_TEXTURES = false (rt_loaded_disable_textures) against the
+reference's render with one-texel textures, and the CLI switches end to end. (The environment map has its own files: tests/test_envmap.py.)"""
 import os
 
 import numpy as np
@@ -93,3 +94,34 @@ def test_cli_switches_reproduce_the_reference_renders(gpu, sg, tmp_path):
     assert out2.read_bytes() == open(os.path.join(envdir, f"open_nolight_envpng_{W}x{H}x{SPP}.ppm"), "rb").read()
     r = subprocess.run([os.path.join(root, "run.sh"), path, str(W), str(H), "1", str(out2)], env=dict(env, RT_ENV_MAP=str(tmp_path / "missing.hdr")), capture_output=True, text=True)
     assert r.returncode == 1 and "environment map" in r.stderr
+
+
+@pytest.mark.parametrize("name", ["room_textured", "features"])
+def test_use_textures_false_equals_the_reference_render(rt, sg, oracle, name, tmp_path):
+    """USE_TEXTURES = false (config.h:31-32): Texture::sample returns the first texel. ref_probe notexrender brings the reference's textures down to one
+    texel (the code path `data.size() == 1` returns the same data[0]) and renders; the oracle on the loader's scene after rt_loaded_disable_textures
+    must write the same bytes, and the image must differ from the textured one (the golden PPM of the same scene)."""
+    ls = load_case(rt, sg, name, tmp_path)
+    n_tex = len(ls.arrays()["textures"])
+    assert n_tex >= 2
+    ls.disable_textures()
+    a = ls.arrays()
+    assert all(t.shape == (1, 1, 4) for t in a["textures"]) and len(a["textures"]) == n_tex
+    orc = oracle.OracleScene(ls)
+    fb, _ = orc.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_REFERENCE)
+    out = tmp_path / "o.ppm"
+    rt.write_ppm(str(out), rt.tonemap(fb))
+    got = out.read_bytes()
+    assert got == open(os.path.join(GOLD, f"{name}_notex_{W}x{H}x{SPP}.ppm"), "rb").read()
+    assert got != open(os.path.join(HERE, "golden", f"{name}_{W}x{H}x{SPP}.ppm"), "rb").read()
+    orc.close()
+
+
+@pytest.mark.gpu
+def test_device_render_without_textures_equals_the_reference_bytes(gpu, sg, oracle, tmp_path):
+    ls = load_case(gpu, sg, "room_textured", tmp_path)
+    ls.disable_textures()
+    dev = gpu.DeviceScene(ls)
+    img, _ = dev.run_raytracer_rgb8(W, H, SPP, rng_mode=gpu.RT_RNG_REFERENCE)
+    assert np.array_equal(img, oracle.read_ppm(os.path.join(GOLD, f"room_textured_notex_{W}x{H}x{SPP}.ppm")))
+    dev.close()
