@@ -147,10 +147,15 @@ def main():
     flat[0, 0] = [200, 90, 40, 129]  # a flat file cannot start with 2 2: keep the first pixel away from it
     write_hdr(os.path.join(OUT, "env_flat.hdr"), flat, rle=False, magic=b"#?RGBE")
     write_hdr(os.path.join(OUT, "env_narrow.hdr"), to_rgbe(sky(5, 4, seed=9)), rle=False)
+    wide = to_rgbe(sky(300, 3, seed=10))  # long scanlines: runs at the 127 limit, dumps at the 128 limit, runs next to dumps
+    wide[0, 10:290] = wide[0, 10]         # one 280-pixel run in every component
+    wide[1, 5:200, 3] = 130               # a constant exponent beside noisy mantissas
+    wide[2, :, :3] = np.random.default_rng(12).integers(1, 255, size=(300, 3))  # nothing to compress: dumps only
+    write_hdr(os.path.join(OUT, "env_wide.hdr"), wide, rle=True)
 
     exp = {}
     with tempfile.TemporaryDirectory() as td:
-        for name in ("env_rle.hdr", "env_flat.hdr", "env_narrow.hdr", "env.png"):
+        for name in ("env_rle.hdr", "env_flat.hdr", "env_narrow.hdr", "env_wide.hdr", "env.png"):
             out = os.path.join(td, "t.bin")
             oracle.ref_probe("texture", os.path.join(OUT, name), 0, 0, out)
             words = np.fromfile(out, dtype=np.uint32)

@@ -31,16 +31,19 @@ def with_env(sg, rt, name, picture, tmp_path):
     return ls
 
 
-@pytest.mark.parametrize("name", ["env_rle.hdr", "env_flat.hdr", "env_narrow.hdr", "env.png"])
+@pytest.mark.parametrize("name", ["env_rle.hdr", "env_flat.hdr", "env_narrow.hdr", "env_wide.hdr", "env.png"])
 def test_picture_decoders_match_the_reference_stb_image(rt, expected, name):
-    """Radiance HDR (run-length encoded, flat with the '#?RGBE' magic, narrower than 8 pixels) and the PNG: the bytes
+    """Radiance HDR (run-length encoded, flat with the '#?RGBE' magic, narrower than 8 pixels, 300 pixels wide with runs and dumps at their
+    length limits) and the PNG: the bytes
     Texture::load_img (stbi_load, 4 channels, 8 bit: stb_image's gamma-2.2 conversion of HDR data) returned in the reference."""
     got = rt.image_decode(os.path.join(ENV, name))
     want = expected["texels_" + name.replace(".", "_")]
     assert got.shape == want.shape
     assert np.array_equal(got, want), int((got != want).sum())
     if name.endswith(".hdr"):
-        assert got[..., 3].min() == 255 and got[..., :3].max() == 255 and got[..., :3].min() == 0  # the sun clamps, exponent 0 is black
+        assert got[..., 3].min() == 255 and got[..., :3].max() == 255  # the sun clamps
+        if name != "env_wide.hdr":
+            assert got[..., :3].min() == 0  # exponent 0 is black
 
 
 def test_hdr_reader_refuses_what_stb_image_refuses(rt, tmp_path):
