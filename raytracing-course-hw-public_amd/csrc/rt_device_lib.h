@@ -1179,6 +1179,49 @@ template <bool STATS, bool ENV = true> DEV V3 bg_at(const DevScene &S, V3 dir, c
     return ld3(S.bg) * mk(c.r, c.g, c.b);
 }
 
+// ---- work tickets of the persistent closest-hit kernels. One head for the whole queue, or (RT_XCD_TICKETS) eight: the queue — in ray order, i.e.
+// sorted by origin cell and direction when a sort ran — is cut into eight contiguous parts and a block starts on part blockIdx.x % 8. Blocks b and
+// b + 8 are observed to share an XCD (MI355X_MICROARCH.md, workgroup dispatch), so the rays one XCD's L2 serves are neighbours in that order; a
+// block whose part has run dry moves on to the next one. Placement changes speed only: every position is handed out exactly once either way.
+// Measured (profiles/r03_variants.txt item 16): S-10M production 250.7 -> 256.2 Msamples/s, parity +0.5 %; S-sponza (cache resident) unchanged.
+#ifndef RT_XCD_TICKETS
+#define RT_XCD_TICKETS 1
+#endif
+struct TicketState {
+    uint32_t part, tried; // wave-uniform
+};
+DEV TicketState ticket_init() { return TicketState{blockIdx.x & 7u, 0u}; }
+// next range [q_lo, q_hi) of at most `chunk` queue positions; false = the whole queue has been handed out
+DEV bool ticket_take(uint32_t *counters, uint32_t n_in, uint32_t chunk, TicketState &ts, uint32_t &q_lo, uint32_t &q_hi) {
+#if RT_XCD_TICKETS
+    const uint32_t n_chunks = (n_in + chunk - 1u) / chunk;
+    for (;;) {
+        if (ts.tried >= 8u)
+            return false;
+        const uint32_t c0 = (uint32_t)(((unsigned long long)n_chunks * ts.part) >> 3), c1 = (uint32_t)(((unsigned long long)n_chunks * (ts.part + 1u)) >> 3);
+        uint32_t t = 0;
+        if ((threadIdx.x & 63u) == 0u)
+            t = atomicAdd(counters + WF_CNT_XCD + ts.part * WF_CNT_XCD_STRIDE, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (c0 + t < c1) {
+            q_lo = (c0 + t) * chunk;
+            q_hi = q_lo + chunk < n_in ? q_lo + chunk : n_in;
+            return true;
+        }
+        ts.part = (ts.part + 1u) & 7u; // this part is used up: help the next one
+        ++ts.tried;
+    }
+#else
+    uint32_t base = 0;
+    if ((threadIdx.x & 63u) == 0u)
+        base = atomicAdd(counters + WF_CNT_TICKET, chunk);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    q_lo = base < n_in ? base : n_in;
+    q_hi = base + chunk < n_in ? base + chunk : n_in;
+    return q_lo != q_hi;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------- one shade() level
 // trace_ray's hit / miss branch (raytracer.h:602-604) + shade (raytracer.h:555-591) for ONE cast result, without the
 // recursion: the caller owns depth bookkeeping and the (emission, scale) fold stack.

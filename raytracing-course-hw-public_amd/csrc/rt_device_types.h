@@ -178,7 +178,7 @@ struct alignas(16) WfFold { // 32 B: one pending shade() frame, `emission + inne
     float e[3], pad0;
     float s[3], pad1;
 };
-enum { WF_CNT_IN = 0, WF_CNT_TICKET = 2, WF_CNT_SLOTS = 3, WF_CNT_WORDS = 16 };
+enum { WF_CNT_IN = 0, WF_CNT_TICKET = 2, WF_CNT_SLOTS = 3, WF_CNT_XCD = 32 /* 8 per-partition work tickets, one 128-byte line each */, WF_CNT_XCD_STRIDE = 32, WF_CNT_WORDS = 32 + 8 * 32 };
 // wf_shade appends a bounce's survivors to WF_STRIPES sub-queues instead of one: a returning atomic on ONE address completes
 // every ~13 ns chip-wide, and one per wave (64 rays) of a 30 M-ray bounce made that single counter the whole kernel's clock
 // (6.3 ms of 6.3 ms; profiles/r02_shade_atomic.txt). Wave slot w of the input queue (positions 64w..64w+63) appends to

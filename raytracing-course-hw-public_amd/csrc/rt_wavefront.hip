@@ -212,6 +212,7 @@ template <bool STATS, bool GB> __global__ __launch_bounds__(256, RT_EXT_WAVES_PE
     uint32_t slot = RT_NONE;
     bool exhausted = n_in == 0; // wave-uniform
     uint32_t q_lo = 0, q_hi = 0; // this wave's private range of queue positions
+    TicketState tks = ticket_init();
 #ifdef RT_DIAG_CYCLES
     // section census of the persistent loop (development build only, no other instrumentation): wave cycles between s_memtime stamps
     unsigned long long dg_refill = 0, dg_node = 0, dg_leaf = 0, dg_pop = 0, dg_store = 0, dg_t = __builtin_amdgcn_s_memtime();
@@ -233,15 +234,8 @@ template <bool STATS, bool GB> __global__ __launch_bounds__(256, RT_EXT_WAVES_PE
             // refill from the wave's private ticket range [q_lo, q_hi); a new range of RT_EXT_CHUNK queue positions is
             // taken with ONE atomic when it runs dry (a single ticket word saturates near 90 M atomics/s, so tickets
             // are taken per chunk, not per refill)
-            if (q_lo == q_hi) {
-                uint32_t base = 0;
-                if ((threadIdx.x & 63u) == 0u)
-                    base = atomicAdd(L.counters + WF_CNT_TICKET, (uint32_t)RT_EXT_CHUNK);
-                base = __builtin_amdgcn_readfirstlane(base);
-                q_lo = base < n_in ? base : n_in;
-                q_hi = base + RT_EXT_CHUNK < n_in ? base + RT_EXT_CHUNK : n_in;
-                exhausted = q_lo == q_hi; // the queue is used up
-            }
+            if (q_lo == q_hi)
+                exhausted = !ticket_take(L.counters, n_in, (uint32_t)RT_EXT_CHUNK, tks, q_lo, q_hi); // false: the queue is used up
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
             const uint32_t avail = q_hi - q_lo;
             if (idle && rank < avail) {
@@ -677,6 +671,8 @@ __global__ __launch_bounds__(64) void wf_advance(uint32_t *counters, uint32_t *s
         counters[WF_CNT_IN] = incl;
         counters[WF_CNT_TICKET] = 0;
     }
+    if (k < 8u)
+        counters[WF_CNT_XCD + k * WF_CNT_XCD_STRIDE] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------------ fold

@@ -253,20 +253,14 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) 
     uint32_t slot = RT_NONE;
     bool exhausted = n_in == 0; // wave-uniform
     uint32_t q_lo = 0, q_hi = 0;
+    TicketState tks = ticket_init();
     for (;;) {
         const bool idle = T.done;
         const unsigned long long im = __ballot(idle);
         const int n_idle = __popcll(im);
         if (!exhausted && (n_idle >= RT_WIDE_REFILL_MIN || n_idle == (int)__popcll(__ballot(1)))) {
-            if (q_lo == q_hi) { // a new range of queue positions, one ticket atomic per chunk
-                uint32_t base = 0;
-                if ((threadIdx.x & 63u) == 0u)
-                    base = atomicAdd(L.counters + WF_CNT_TICKET, (uint32_t)RT_WIDE_CHUNK);
-                base = __builtin_amdgcn_readfirstlane(base);
-                q_lo = base < n_in ? base : n_in;
-                q_hi = base + RT_WIDE_CHUNK < n_in ? base + RT_WIDE_CHUNK : n_in;
-                exhausted = q_lo == q_hi;
-            }
+            if (q_lo == q_hi) // a new range of queue positions, one ticket atomic per chunk
+                exhausted = !ticket_take(L.counters, n_in, (uint32_t)RT_WIDE_CHUNK, tks, q_lo, q_hi);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
             const uint32_t avail = q_hi - q_lo;
             if (idle && rank < avail) {
