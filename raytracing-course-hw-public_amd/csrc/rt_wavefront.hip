@@ -644,6 +644,10 @@ __global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLa
             const float ax = __builtin_fabsf(r0.w), ay = __builtin_fabsf(r1.x), az = __builtin_fabsf(r1.y);
             const uint32_t sub = (ax > ay ? 1u : 0u) | (ay > az ? 2u : 0u) | (ax > az ? 4u : 0u);
             key = (((morton << 3) | oct) << 3) | sub;
+        } else if (L.sort_mode == 5) { // octant, 64^3 cell, then the sub-cone (24 bits)
+            const float ax = __builtin_fabsf(r0.w), ay = __builtin_fabsf(r1.x), az = __builtin_fabsf(r1.y);
+            const uint32_t sub = (ax > ay ? 1u : 0u) | (ay > az ? 2u : 0u) | (ax > az ? 4u : 0u);
+            key = (oct << 21) | (morton << 3) | sub;
         }
         L.sort_keys[0][j] = key;
         L.sort_vals[0][j] = pos;
@@ -866,7 +870,7 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
             WF_LAUNCH(wf_sort_keys, dim3(kb > 0 ? kb : 1), block, 0, stream, S, L, sort ? 0 : 1, bound);
             if (sort) {
                 size_t tmp = L.sort_temp_bytes;
-                hipError_t se = rocprim::radix_sort_pairs(L.sort_temp, tmp, L.sort_keys[0], L.sort_keys[1], L.sort_vals[0], L.sort_vals[1], (size_t)bound, 0u, L.sort_mode == 4 ? 24u : 21u, stream);
+                hipError_t se = rocprim::radix_sort_pairs(L.sort_temp, tmp, L.sort_keys[0], L.sort_keys[1], L.sort_vals[0], L.sort_vals[1], (size_t)bound, 0u, L.sort_mode >= 4 ? 24u : 21u, stream);
                 if (se != hipSuccess)
                     return se;
             }
