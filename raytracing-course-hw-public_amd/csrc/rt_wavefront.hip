@@ -55,7 +55,8 @@ using ShadeStack = StackMemT<RT_SHADE_LDS_DEPTH>;
 #define RT_EXT_POP_ONCE 1 /* bounded unwind: one stack pop per trip instead of an inner loop until no lane unwinds */
 #endif
 #ifndef RT_EXT_CHUNK
-#define RT_EXT_CHUNK 128u /* queue positions a wave takes per ticket atomic */
+#define RT_EXT_CHUNK 64u /* queue positions a wave takes per ticket atomic (128 until the tickets were partitioned: with eight heads the atomics are cheap
+                            and the last ticket of a part is one batch of work, not two: + 0.7 % S-sponza, + 1 % S-10M, profiles/r03_variants.txt item 21) */
 #endif
 #ifndef RT_EXT_REFILL_MIN
 #define RT_EXT_REFILL_MIN 16 /* refill a wave's idle lanes once this many have finished (a refill stalls the wave on the ray loads) */

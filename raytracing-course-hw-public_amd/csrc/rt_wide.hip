@@ -27,7 +27,7 @@ namespace {
 #define RT_WIDE_LDS_DEPTH 8 /* stacked node groups kept in LDS per lane (8 B each); deeper ones spill to the overflow workspace */
 #endif
 #ifndef RT_WIDE_CHUNK
-#define RT_WIDE_CHUNK 128u
+#define RT_WIDE_CHUNK 64u
 #endif
 #ifndef RT_WIDE_REFILL_MIN
 #define RT_WIDE_REFILL_MIN 16
