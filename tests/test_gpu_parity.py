@@ -153,11 +153,11 @@ def test_queue_shapes_match_oracle(pairs, gpu, shape):
     """wf_shade appends to 64 sub-queues whose regions are whole wave slots; the next bounce maps the dense ray index back to
     a slot (with a sort from 4096 rays up, directly below). Path counts below one wave, not multiples of 64, exactly at and
     across the 4096-ray sort threshold (a queue that shrinks below it between bounces) all give the oracle's framebuffer
-    bit for bit, with sorting on and off."""
+    bit for bit, with every ray-order key (RT_WF_SORT 1..5; 5 is the default) and with sorting off."""
     dev, orc, _ = pairs["room_manylights"]
     W, H, SPP = shape
     ofb, ost = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=99)
-    for sort in ("4", "0"):
+    for sort in ("5", "4", "3", "2", "1", "0") if shape == (96, 50, 2) else ("5", "0"):
         old = os.environ.get("RT_WF_SORT")
         os.environ["RT_WF_SORT"] = sort
         try:
