@@ -68,7 +68,7 @@ sys.path.insert(0, ROOT)
 SHARD_ROWS = 8
 SEED = 0x5EED5EED
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 CONFIG4_SPP = 1000
 
 WORKLOADS = {
@@ -87,6 +87,28 @@ MODES = {
     "global": dict(suffix="-gbest", wide=False, gbest=True, text="reference tree, global-best pruning (production)"),
     "wide": dict(suffix="-wide", wide=True, gbest=False, text="8-wide quantised BVH, global-best culling, octant order (production build RT_BUILD_WIDE)"),
 }
+
+
+def tuning_from_env(env=None):
+    """(render tuning kwargs, build option kwargs) from the development variables the sweep scripts under tools/ set. Since ABI 4 the
+    library reads NO environment variable: this file (and the CLI, csrc/host/main.cpp) turns them into rt_params / rt_build_options fields."""
+    env = os.environ if env is None else env
+    render, build = {}, {}
+    if "RT_WF_SORT" in env:
+        render["sort_mode"] = int(env["RT_WF_SORT"]) + 1  # RT_SORT_OFF = 1, then the keys in RT_SORT_* order
+    if "RT_WF_PACKET" in env:
+        render["packet_mode"] = 2 if int(env["RT_WF_PACKET"]) else 1  # RT_PACKET_ON / RT_PACKET_OFF
+    if "RT_WF_PACKET_MIN" in env:
+        render["packet_min_lanes"] = float(env["RT_WF_PACKET_MIN"])
+    if "RT_WF_MAX_PATHS" in env:
+        render["max_paths"] = int(float(env["RT_WF_MAX_PATHS"]))
+    if env.get("RT_DEVICE_BUILDER") == "lbvh":
+        build["device_builder"] = 1
+    for var, field, conv in (("RT_PLOC_RADIUS", "ploc_radius", int), ("RT_LBVH_LEAF", "lbvh_leaf_tris", int), ("RT_NODE_ORDER", "node_order", int),
+                             ("RT_WIDE_ORDER", "wide_order", int), ("RT_WIDE_COST_NODE", "wide_cost_node", float), ("RT_WIDE_COST_TRI", "wide_cost_tri", float)):
+        if var in env:
+            build[field] = conv(env[var])
+    return render, build
 
 
 def kernel_source_hash() -> str:
@@ -205,9 +227,10 @@ class Runner:
         self.launcher, self.rank, self.world, self.n_gpus, self.backend, self.film = launcher, rank, world, n_gpus, backend, film
         self.workload_id = (wl_name if full_size is True else f"{wl_name}-{full_size}" if full_size else f"{wl_name}-custom") + ("-dev" if device_bvh else "") + self.m["suffix"]
         self.device = torch.device("cuda", local_rank)
+        self.tuning, build_opts = tuning_from_env()
         t0 = time.time()
         dev_arg = list(range(n_gpus)) if launcher == "group" else local_rank
-        self.dev = rt.DeviceScene(scene, device=dev_arg, wide=self.m["wide"], device_bvh=device_bvh)
+        self.dev = rt.DeviceScene(scene, device=dev_arg, wide=self.m["wide"], device_bvh=device_bvh, **build_opts)
         self.t_create = time.time() - t0
         self.build_times = self.dev.build_times()
         self.ranks_formed = self.dev.n_devices if launcher == "group" else world
@@ -223,8 +246,8 @@ class Runner:
     def shard_kw(self):
         # torchrun: this rank renders its blocks; group: the library shards over its own GPUs (shard_count must stay 1)
         if self.world > 1:
-            return dict(shard_index=self.rank, shard_count=self.world, shard_block=self.block)
-        return dict(shard_block=self.block if self.launcher == "group" else 0)
+            return dict(self.tuning, shard_index=self.rank, shard_count=self.world, shard_block=self.block)
+        return dict(self.tuning, shard_block=self.block if self.launcher == "group" else 0)
 
     def step(self):
         if self.film:
@@ -259,6 +282,7 @@ class Runner:
             elapsed = float(t.item())
         self.elapsed, self.steps = elapsed, steps
         self.kernel_ms, self.dom_ms, self.dom_launches = kernel_ms, dom_ms, dom_launches
+        self.last_stats = st
         return float(self.n_pix) * self.spp * steps / elapsed / 1e6
 
     def roofline(self):

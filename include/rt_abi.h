@@ -41,7 +41,9 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3u /* 2: rt_scene_desc carries analytic primitives (scene-txt front end); 3: bg_texture (environment map) */
+#define RT_ABI_VERSION 4u /* 2: rt_scene_desc carries analytic primitives (scene-txt front end); 3: bg_texture (environment map);
+                             4: every tuning knob is a field (rt_build_options, rt_params.sort_mode / packet_mode / max_paths ...): the library
+                                reads no environment variable; progress callback; packet census in rt_stats */
 #define RT_TEX_NONE (-1)
 #define RT_ALL_DEVICES (-1) /* rt_create: one scene replica on every visible GPU + an RCCL communicator over them */
 
@@ -111,6 +113,32 @@ typedef struct rt_primitive_desc {
     float rotation[4];    /* quaternion x y z w (order of sample_data and of geometry.h:154-156) */
 } rt_primitive_desc;
 
+/* Build-time tuning of rt_create. The reference's knobs are constexpr (config.h:7-47); these are per scene, and all-zero means
+ * "the measured default" for every field, so a zero-initialised descriptor behaves as before. (Up to ABI 3 these were environment
+ * variables read inside the library; now only the CLI, host/main.cpp, and bench.py translate environment into fields.) */
+enum { RT_BUILDER_PLOC = 0, RT_BUILDER_LBVH = 1 };
+typedef struct rt_build_options {
+    uint32_t device_builder;  /* RT_BUILD_DEVICE_LBVH only: RT_BUILDER_PLOC (default; falls back to the radix tree when deeper than the
+                                 traversal stacks) or RT_BUILDER_LBVH (Karras radix tree + refit) */
+    uint32_t ploc_radius;     /* PLOC nearest-neighbour search radius, 1..32; 0 = 8 (profiles/r03_wide.txt) */
+    uint32_t lbvh_leaf_tris;  /* triangles per leaf of the device-built binary tree, 1..8; 0 = 1 */
+    uint32_t node_order;      /* order of the reference-topology tree's inner nodes in HBM: 0 pre-order (default), 1 breadth first,
+                                 2 sibling pairs. Placement only: hits and counters do not depend on it */
+    float wide_cost_node;     /* surface-area cost of a wide-node visit in the collapse; 0 = 1.0 */
+    float wide_cost_tri;      /* ... of a triangle test; 0 = 0.3 */
+    uint32_t wide_order;      /* order of the WideNode records in HBM: RT_WIDE_ORDER_* (placement only) */
+    uint32_t reserved;        /* 0 */
+} rt_build_options;
+/* Placement of the 8-wide tree's records (csrc/wide_build.cpp, csrc/rt_bvh_device.hip). Children of one node are always
+ * consecutive (the traversal finds child i at child_base + rank); what differs is where the groups of siblings go. */
+enum {
+    RT_WIDE_ORDER_DEFAULT = 0,  /* what measured best for the builder in use */
+    RT_WIDE_ORDER_LEVEL = 1,    /* level by level (breadth first): the device builder's natural emission order */
+    RT_WIDE_ORDER_DFS = 2,      /* sibling groups in depth-first order of their parents */
+    RT_WIDE_ORDER_TREELET = 3   /* van-Emde-Boas-like: a node's children group, then recursively each child's subtree in blocks of
+                                   three levels, so that a descent of three levels stays inside one contiguous region */
+};
+
 typedef struct rt_scene_desc {
     uint32_t abi_version; /* RT_ABI_VERSION */
     uint32_t n_triangles;
@@ -131,7 +159,8 @@ typedef struct rt_scene_desc {
     uint32_t build_flags; /* RT_BUILD_* */
     int32_t bg_texture;   /* Scene::bg (scene.h:81; main.cpp:29-31, config.h:36-38 USE_ENV_MAP / ENV_MAP_PATH): index into `textures` of the
                              environment map that Scene::bg_at (scene.h:83-89) samples by direction, RT_TEX_NONE = the reference's default, the
-                             1x1 WHITE_TEXTURE (a constant bg_color background). Loaders: rt_loaded_scene_set_env_map (rt_host.h) */
+                             1x1 WHITE_TEXTURE (a constant bg_color background). Loaders: rt_loaded_set_env_map (rt_host.h) */
+    rt_build_options build; /* all-zero = defaults */
 } rt_scene_desc;
 /* How rt_create builds the scene BVH (BVH::build, bvh.h:262-393):
  *   RT_BUILD_REFERENCE (default): on the host, in the reference's exact topology (same SAH sweep, same std::sort
@@ -139,15 +168,44 @@ typedef struct rt_scene_desc {
  *   RT_BUILD_DEVICE_LBVH: on the GPU (Morton sort + Karras radix tree + refit, csrc/rt_bvh_device.hip), tens of milliseconds
  *       for 10^7 triangles instead of seconds. Same closest hits (identical t), but a different topology: ties between
  *       equal-t triangles may resolve differently and the counters differ. Production mode for big scenes; also selected by
- *       the environment variable RT_BVH_DEVICE=1. The light BVH (emissive triangles only) is always built on the host.
+ *       the CLI's RT_BVH_DEVICE=1. The light BVH (emissive triangles only) is always built on the host.
  *   RT_BUILD_WIDE (may be combined with either binary builder): the binary tree is collapsed into an 8-wide tree whose nodes
  *       hold eight child boxes quantised conservatively to 8 bits per plane (80 B per node), chosen by a surface-area
  *       dynamic program; the wavefront pipeline then walks THAT tree with global-best culling and octant-ordered slots
  *       (csrc/wide_build.cpp, csrc/rt_wide.hip). Production mode: the closest hit is the reference's (t bit for bit; another
  *       index only on exact ties) with far fewer memory accesses per ray; event counters count wide nodes. The megakernel /
- *       reference-RNG parity renders are refused on such a scene (RT_ERR_UNSUPPORTED). Environment: RT_BVH_WIDE=1. */
-enum { RT_BUILD_REFERENCE = 0, RT_BUILD_DEVICE_LBVH = 1, RT_BUILD_WIDE = 2 };
+ *       reference-RNG parity renders are refused on such a scene (RT_ERR_UNSUPPORTED). The CLI sets it for RT_BVH_WIDE=1.
+ *   RT_BUILD_WIDE_HOST_COLLAPSE (development; with RT_BUILD_DEVICE_LBVH | RT_BUILD_WIDE): read the device-built binary tree back and
+ *       collapse it on the host (wide_build.cpp) instead of on the device — the cross-check of the device collapse.
+ *   RT_BUILD_LIGHTS_GLOBAL (development): never stage the light BVH in wf_shade's LDS.
+ *   RT_BUILD_GROUP_COPY (tests; multi-GPU scenes): replace the RCCL exchange by peer copies, which lets a one-GPU box rehearse G > 1
+ *       with repeated ordinals (RCCL refuses those). RT_BUILD_GROUP_SELF_EXCHANGE (tests): the first GPU's own blocks also travel
+ *       through ncclSend / ncclRecv, which exercises the RCCL path with G = 1. */
+enum { RT_BUILD_REFERENCE = 0, RT_BUILD_DEVICE_LBVH = 1, RT_BUILD_WIDE = 2, RT_BUILD_WIDE_HOST_COLLAPSE = 4, RT_BUILD_LIGHTS_GLOBAL = 8,
+       RT_BUILD_GROUP_COPY = 16, RT_BUILD_GROUP_SELF_EXCHANGE = 32 };
 #define RT_MAX_PRIMITIVES 4096u
+
+/* Progress report of a render: called on the calling thread after every finished pass (pixel tile x sample range) of a single-GPU
+ * scene, `done` of `total` passes; a multi-GPU scene reports once per GPU that finished, from that GPU's host thread (calls are
+ * serialised). The reference prints "%d/%d     \r" per finished span (raytracer.h:647); the CLI does the same per pass under RT_VERBOSE. */
+typedef void (*rt_progress_fn)(uint32_t done, uint32_t total, void *user);
+/* Coherence sort of the rays of bounces >= 1 (wavefront pipeline; ordering never changes a result) */
+enum {
+    RT_SORT_AUTO = 0,             /* octant + cell + sub-cone where the tree does not fit the caches, none for a cache-resident wide tree */
+    RT_SORT_OFF = 1,
+    RT_SORT_CELL_OCTANT = 2,      /* 64^3 origin cell, direction octant (21 bits) */
+    RT_SORT_COARSE_CELL_DIR = 3,  /* 16^3 cell, 9-bit direction code */
+    RT_SORT_OCTANT_CELL = 4,      /* octant, 64^3 cell */
+    RT_SORT_CELL_OCTANT_CONE = 5, /* cell, octant, sub-cone (24 bits) */
+    RT_SORT_OCTANT_CELL_CONE = 6  /* octant, cell, sub-cone: what AUTO picks */
+};
+/* Primary rays as 64-ray packets (wf_extend_packet / wf_extend_wide_packet) */
+enum {
+    RT_PACKET_AUTO = 0, /* from 16 (binary tree) / 4 (wide tree) samples per pixel and pass, until the kernel's own census of a pass
+                           shows fewer than packet_min_lanes lanes served per trip for this image size / samples per pass */
+    RT_PACKET_OFF = 1,
+    RT_PACKET_ON = 2
+};
 
 typedef struct rt_params {
     uint32_t width;
@@ -163,6 +221,15 @@ typedef struct rt_params {
     uint32_t shard_count;
     uint32_t shard_block;
     uint32_t flags; /* RT_FLAG_* */
+    /* ---- ABI 4: tuning (all-zero = the measured defaults) and progress */
+    uint32_t sort_mode;       /* RT_SORT_* */
+    uint32_t packet_mode;     /* RT_PACKET_* */
+    float packet_min_lanes;   /* RT_PACKET_AUTO: lanes served per packet trip below which later passes use the per-lane kernel;
+                                 0 = 33 (binary tree, profiles/r02_packet.txt) / 20 (wide tree, profiles/r03_wide.txt) */
+    uint32_t reserved0;       /* 0 */
+    uint64_t max_paths;       /* paths (pixel, sample) per pass of the wavefront pipeline; 0 = 64 M, capped by free device memory */
+    rt_progress_fn progress;  /* may be NULL */
+    void *progress_user;
 } rt_params;
 
 enum {
@@ -182,7 +249,7 @@ enum {
                               against the GLOBAL best hit so far, which visits a subset of the reference's nodes. The
                               closest hit is the same (t bit for bit) except where a triangle's t rounds below its own
                               box's entry distance, or on exact ties; the event counters differ. Off by default: the
-                              parity mode reproduces the reference's order and counters. Environment: RT_TRAVERSAL=global. */
+                              parity mode reproduces the reference's order and counters. The CLI sets it for RT_TRAVERSAL=global. */
 };
 
 /* Per-render statistics (optional out-parameter). Counters are layout independent event counts in the
@@ -205,7 +272,10 @@ typedef struct rt_stats {
     double dominant_ms;      /* summed device time of the dominant kernel's launches (wf_extend; the megakernel when
                                 that path is used), one HIP event pair per launch */
     uint32_t dominant_launches;
-    uint32_t reserved;
+    uint32_t packet_lanes_x100; /* last packet census read back: lanes served per packet trip x 100 (0: no packet pass ran, or none
+                                   has been read back yet) */
+    uint32_t passes;            /* passes (pixel tile x sample range) of this render */
+    uint32_t packet_passes;     /* ... whose primary rays went through the packet kernel */
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* opaque: device-resident scene + both BVHs */
@@ -226,9 +296,7 @@ void rt_destroy(rt_scene *scene);
  * the first GPU with RT_FLAG_DEVICE_FB). The image is bit-identical to a single-GPU render (per-(pixel, sample) seeding).
  * The probe entry points (rt_cast_rays, rt_light_pdf, rt_bvh_info, rt_film_rgb8) run on the first GPU's replica.
  * Errors: RT_ERR_COMM when RCCL cannot be loaded, refuses the device set, or an exchange fails.
- * Environment (tests): RT_GROUP_TRANSPORT=copy replaces the RCCL exchange by peer copies (lets a one-GPU box rehearse
- * G > 1 with repeated ordinals, which RCCL refuses); RT_GROUP_SELF_EXCHANGE=1 also sends the first GPU's own blocks
- * through ncclSend/ncclRecv (exercises the RCCL path with G = 1). */
+ * Tests: build_flags RT_BUILD_GROUP_COPY / RT_BUILD_GROUP_SELF_EXCHANGE (above). */
 int rt_create_on(const rt_scene_desc *desc, const int *devices, int n_devices, rt_scene **out);
 int rt_scene_device_count(const rt_scene *scene); /* GPUs rendering for this scene (1 for rt_create on one device) */
 

@@ -25,6 +25,27 @@ from ._ctypes_abi import (
     RT_FLAG_DEVICE_FB,
     RT_BUILD_DEVICE_LBVH,
     RT_BUILD_WIDE,
+    RT_BUILD_WIDE_HOST_COLLAPSE,
+    RT_BUILD_LIGHTS_GLOBAL,
+    RT_BUILD_GROUP_COPY,
+    RT_BUILD_GROUP_SELF_EXCHANGE,
+    RT_BUILDER_PLOC,
+    RT_BUILDER_LBVH,
+    RT_WIDE_ORDER_DEFAULT,
+    RT_WIDE_ORDER_LEVEL,
+    RT_WIDE_ORDER_DFS,
+    RT_WIDE_ORDER_TREELET,
+    RT_SORT_AUTO,
+    RT_SORT_OFF,
+    RT_SORT_CELL_OCTANT,
+    RT_SORT_COARSE_CELL_DIR,
+    RT_SORT_OCTANT_CELL,
+    RT_SORT_CELL_OCTANT_CONE,
+    RT_SORT_OCTANT_CELL_CONE,
+    RT_PACKET_AUTO,
+    RT_PACKET_OFF,
+    RT_PACKET_ON,
+    RT_PROGRESS_FN,
     RT_FLAG_MEGAKERNEL,
     RT_FLAG_GLOBAL_BEST,
     RT_CAST_PROBE,
@@ -152,21 +173,44 @@ def _as_desc(scene) -> Tuple[RtSceneDesc, object]:
     return holder.desc, holder
 
 
+def _apply_tuning(p: RtParams, tuning: dict):
+    """rt_params' ABI-4 fields from keyword arguments; returns the ctypes callback object (if any), to be kept alive by the caller."""
+    cb = None
+    for k, v in tuning.items():
+        if k == "progress":
+            if v is not None:
+                cb = RT_PROGRESS_FN(lambda done, total, user, f=v: f(done, total))
+                p.progress = cb
+        elif k in ("sort_mode", "packet_mode", "max_paths"):
+            setattr(p, k, int(v))
+        elif k == "packet_min_lanes":
+            p.packet_min_lanes = float(v)
+        else:
+            raise TypeError(f"rt_params has no tuning field {k!r}")
+    return cb
+
+
 class DeviceScene:
     """Device-resident scene + both BVHs: the RaytracerStaticContext of raytracer.h:434-455, in HBM."""
 
-    def __init__(self, scene, device=0, device_bvh: bool = False, wide: bool = False):
+    def __init__(self, scene, device=0, device_bvh: bool = False, wide: bool = False, build_flags: int = 0, **build_options):
         """`device_bvh`: build the scene BVH on the GPU (RT_BUILD_DEVICE_LBVH: production mode, different topology) instead
         of the reference-topology host build. `wide`: collapse that binary tree into the 8-wide quantised tree (RT_BUILD_WIDE:
-        production traversal). `device`: a HIP ordinal; RT_ALL_DEVICES (-1) for one replica per visible GPU + an RCCL communicator; or a list
-        of ordinals (rt_create_on). Multi-GPU scenes shard every render over their GPUs and gather on the first one."""
+        production traversal). `build_flags`: further RT_BUILD_* bits; `build_options`: rt_build_options fields by name (device_builder,
+        ploc_radius, lbvh_leaf_tris, node_order, wide_cost_node, wide_cost_tri, wide_order). `device`: a HIP ordinal; RT_ALL_DEVICES (-1)
+        for one replica per visible GPU + an RCCL communicator; or a list of ordinals (rt_create_on). Multi-GPU scenes shard every render
+        over their GPUs and gather on the first one."""
         desc, keep = _as_desc(scene)
         self._keep = keep
         self._h = C.c_void_p()
-        if device_bvh or wide:  # a private copy of the descriptor with the build flags set
+        if device_bvh or wide or build_flags or build_options:  # a private copy of the descriptor with the build flags set
             d2 = RtSceneDesc()
             C.memmove(C.byref(d2), C.byref(desc), C.sizeof(RtSceneDesc))
-            d2.build_flags = (RT_BUILD_DEVICE_LBVH if device_bvh else 0) | (RT_BUILD_WIDE if wide else 0)
+            d2.build_flags = int(desc.build_flags) | (RT_BUILD_DEVICE_LBVH if device_bvh else 0) | (RT_BUILD_WIDE if wide else 0) | int(build_flags)
+            for k, v in build_options.items():
+                if not hasattr(d2.build, k):
+                    raise TypeError(f"rt_build_options has no field {k!r}")
+                setattr(d2.build, k, v)
             desc = d2
         if isinstance(device, (list, tuple)):
             devs = (C.c_int * len(device))(*[int(d) for d in device])
@@ -204,12 +248,16 @@ class DeviceScene:
         counters: bool = False,
         megakernel: bool = False,
         global_best: bool = False,
+        **tuning,
     ):
         """run_raytracer(scene, image) (raytracer.h:629): returns (linear float framebuffer (H,W,3), stats dict).
         With `device_fb` (a device pointer) the framebuffer stays in HBM and None is returned for it.
-        `counters=True` runs the instrumented kernel variant and fills the event counters of the stats."""
+        `counters=True` runs the instrumented kernel variant and fills the event counters of the stats.
+        `tuning`: rt_params fields by name — sort_mode (RT_SORT_*), packet_mode (RT_PACKET_*), packet_min_lanes, max_paths,
+        progress (a callable (done, total))."""
         p = RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block,
                      (RT_FLAG_COUNTERS if counters else 0) | (RT_FLAG_MEGAKERNEL if megakernel else 0) | (RT_FLAG_GLOBAL_BEST if global_best else 0))
+        keep_cb = _apply_tuning(p, tuning)  # noqa: F841 (keeps the ctypes callback alive for the call)
         st = RtStats()
         if device_fb:
             p.flags |= RT_FLAG_DEVICE_FB
@@ -233,10 +281,12 @@ class DeviceScene:
         device_rgb8: int = 0,
         rng_mode: int = RT_RNG_DEVICE,
         global_best: bool = False,
+        **tuning,
     ):
         """run_raytracer(scene, image) with the reference's own output type (image.h:40-42): the tone-mapped rgb8 image,
-        film applied on the device. Returns ((H,W,3) uint8 array or None with `device_rgb8`, stats dict)."""
+        film applied on the device. Returns ((H,W,3) uint8 array or None with `device_rgb8`, stats dict). `tuning`: as run_raytracer."""
         p = RtParams(width, height, samples, rng_mode, seed, shard_index, shard_count, shard_block, RT_FLAG_GLOBAL_BEST if global_best else 0)
+        keep_cb = _apply_tuning(p, tuning)  # noqa: F841
         st = RtStats()
         if device_rgb8:
             p.flags |= RT_FLAG_DEVICE_FB

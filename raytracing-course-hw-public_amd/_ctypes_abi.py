@@ -9,12 +9,20 @@ import ctypes as C
 
 import numpy as np
 
-RT_ABI_VERSION = 3
+RT_ABI_VERSION = 4
 RT_PRIM_ELLIPSOID = 1
 RT_PRIM_PLANE = 2
 RT_BUILD_REFERENCE = 0
 RT_BUILD_DEVICE_LBVH = 1
 RT_BUILD_WIDE = 2
+RT_BUILD_WIDE_HOST_COLLAPSE = 4
+RT_BUILD_LIGHTS_GLOBAL = 8
+RT_BUILD_GROUP_COPY = 16
+RT_BUILD_GROUP_SELF_EXCHANGE = 32
+RT_BUILDER_PLOC, RT_BUILDER_LBVH = 0, 1
+RT_WIDE_ORDER_DEFAULT, RT_WIDE_ORDER_LEVEL, RT_WIDE_ORDER_DFS, RT_WIDE_ORDER_TREELET = range(4)
+RT_SORT_AUTO, RT_SORT_OFF, RT_SORT_CELL_OCTANT, RT_SORT_COARSE_CELL_DIR, RT_SORT_OCTANT_CELL, RT_SORT_CELL_OCTANT_CONE, RT_SORT_OCTANT_CELL_CONE = range(7)
+RT_PACKET_AUTO, RT_PACKET_OFF, RT_PACKET_ON = range(3)
 RT_TEX_NONE = -1
 RT_RNG_DEVICE = 0
 RT_RNG_REFERENCE = 1
@@ -80,6 +88,19 @@ class RtPrimitiveDesc(C.Structure):
     ]
 
 
+class RtBuildOptions(C.Structure):
+    _fields_ = [
+        ("device_builder", C.c_uint32),
+        ("ploc_radius", C.c_uint32),
+        ("lbvh_leaf_tris", C.c_uint32),
+        ("node_order", C.c_uint32),
+        ("wide_cost_node", C.c_float),
+        ("wide_cost_tri", C.c_float),
+        ("wide_order", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
 class RtSceneDesc(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32),
@@ -100,7 +121,11 @@ class RtSceneDesc(C.Structure):
         ("primitives", C.POINTER(RtPrimitiveDesc)),
         ("build_flags", C.c_uint32),
         ("bg_texture", C.c_int32),
+        ("build", RtBuildOptions),
     ]
+
+
+RT_PROGRESS_FN = C.CFUNCTYPE(None, C.c_uint32, C.c_uint32, C.c_void_p)
 
 
 class RtParams(C.Structure):
@@ -114,6 +139,13 @@ class RtParams(C.Structure):
         ("shard_count", C.c_uint32),
         ("shard_block", C.c_uint32),
         ("flags", C.c_uint32),
+        ("sort_mode", C.c_uint32),
+        ("packet_mode", C.c_uint32),
+        ("packet_min_lanes", C.c_float),
+        ("reserved0", C.c_uint32),
+        ("max_paths", C.c_uint64),
+        ("progress", RT_PROGRESS_FN),
+        ("progress_user", C.c_void_p),
     ]
 
 
@@ -135,7 +167,9 @@ class RtStats(C.Structure):
         ("total_ms", C.c_double),
         ("dominant_ms", C.c_double),
         ("dominant_launches", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("packet_lanes_x100", C.c_uint32),
+        ("passes", C.c_uint32),
+        ("packet_passes", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:
@@ -277,6 +311,8 @@ class DescHolder:
         d.n_primitives = len(prims)
         d.primitives = self.primitives
         d.build_flags = int(getattr(scene, "build_flags", 0))
+        for k, v in (getattr(scene, "build_options", None) or {}).items():  # rt_build_options fields by name
+            setattr(d.build, k, v)
         d.bg_texture = int(getattr(scene, "bg_texture", -1))  # Scene::bg: index into textures, -1 = the white default
         self.desc = d
 

@@ -246,7 +246,7 @@ HostBvh build_bvh(const float *positions, uint32_t n_total, const std::vector<ui
     return out;
 }
 
-FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions) {
+FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions, uint32_t node_order) {
     FlatBvh f;
     if (bvh.root == RT_NONE)
         return f;
@@ -264,7 +264,7 @@ FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions) {
         t.flags = 0;
         t.pad = 0;
     }
-    // inner nodes get device indices in pre-order among inner nodes (RT_NODE_ORDER, development: 1 = breadth first,
+    // inner nodes get device indices in pre-order among inner nodes (rt_build_options.node_order, development: 1 = breadth first,
     // 2 = sibling pairs: a node's two inner children adjacent, subtrees depth first)
     std::vector<uint32_t> dev_index(bvh.nodes.size(), RT_NONE);
     uint32_t n_inner = 0;
@@ -276,8 +276,7 @@ FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions) {
             f.tris[nd.obj_begin].flags |= 2u;   // first triangle of its leaf
         }
     }
-    const char *order_env = std::getenv("RT_NODE_ORDER");
-    const int order_mode = order_env ? std::atoi(order_env) : 0;
+    const int order_mode = (int)node_order;
     if (order_mode == 1 && is_inner(bvh.root)) {
         std::vector<uint32_t> q{bvh.root};
         for (size_t h = 0; h < q.size(); ++h) {

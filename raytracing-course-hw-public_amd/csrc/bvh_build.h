@@ -29,6 +29,7 @@ struct FlatBvh {
     uint32_t root = RT_NONE;
     bool fast_ok = true; // all box coordinates are 0 or within [2^-37, 2^40] in magnitude
 };
-FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions);
+// `node_order` (rt_build_options.node_order): 0 pre-order among inner nodes, 1 breadth first, 2 sibling pairs (placement only)
+FlatBvh flatten_bvh(const HostBvh &bvh, const float *positions, uint32_t node_order = 0);
 
 } // namespace rt

@@ -116,6 +116,12 @@ extern "C" int rt_hdr_decode_file(const char *path, uint32_t *w_out, uint32_t *h
         const long width = std::strtol(end + 3, nullptr, 10);
         if (height <= 0 || width <= 0 || height > (1 << 24) || width > (1 << 24) || (uint64_t)width * (uint64_t)height > (1ull << 28))
             throw HdrError{"HDR picture too large or empty"};
+        // The data must be able to hold the picture: flat pixels take 4 bytes each, and the run-length code spends at least 8 bytes per 127
+        // pixels (a maximal run per channel), i.e. no valid file carries more than 16 pixels per byte. Without this a header of a few
+        // dozen bytes could claim 2^28 pixels: a 1 GiB allocation and, as get8() returns 0 at the end of the data like stb_image's,
+        // seconds of pow() over pixels that do not exist.
+        if ((uint64_t)width * (uint64_t)height > 16ull * (uint64_t)(file.size() - r.pos) + 16ull)
+            throw HdrError{"HDR picture larger than its data can hold"};
         px = static_cast<uint8_t *>(std::malloc((size_t)width * height * 4));
         if (!px)
             return rt::fail(RT_ERR_OOM, "HDR: out of memory");

@@ -39,7 +39,7 @@ namespace {
 
 // Triangles per leaf. Measured (tools/lbvh_probe.py, profiles/r02_lbvh.txt): 1 renders fastest at both scene sizes
 // (262 k triangles: 83 ms against 107 ms on the reference's tree; 10^7: 166 against 141 ms), 2 and 4 are slower (loose leaf
-// boxes along the Morton curve), so the default is one triangle per leaf; RT_LBVH_LEAF (1..8) overrides it for experiments.
+// boxes along the Morton curve), so the default is one triangle per leaf; rt_build_options.lbvh_leaf_tris (1..8) overrides it for experiments.
 constexpr uint32_t LEAF_TRIS_DEFAULT = 1;
 
 __device__ __forceinline__ uint32_t enc_f(float f) { // order-preserving float -> uint
@@ -808,8 +808,8 @@ hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBv
     float *pos, *nrm, *tan, *uv;
     uint32_t *mat, *keys[2], *vals[2], *bounds, *leaf_parent, *node_parent, *arrived, *fast_bad;
     uint32_t leaf_tris = LEAF_TRIS_DEFAULT;
-    if (const char *e = std::getenv("RT_LBVH_LEAF"))
-        leaf_tris = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
+    if (d->build.lbvh_leaf_tris)
+        leaf_tris = std::min(8u, std::max(1u, d->build.lbvh_leaf_tris));
     // the wide collapse regroups single-triangle leaves itself; scenes of a handful of triangles take the host collapse (rt_scene.cpp)
     wide = wide && n > 8u;
     if (wide)
@@ -886,18 +886,17 @@ hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBv
     BUILD_TRY(hipMemsetAsync(leaf_parent, 0xFF, 4ull * n_leaves, stream)); // RT_NONE: a single leaf has no parent
     const int lblocks = (int)std::min<uint64_t>(((uint64_t)n_leaves + 255) / 256, 256u * 16u);
     BUILD_TRY(RT_LAUNCH_CHECKED(k_leaves, dim3(lblocks), dim3(256), 0, stream, A));
-    // binary tree over the leaves: PLOC (default) or the Karras radix tree + refit (RT_DEVICE_BUILDER=lbvh; also the fallback when
+    // binary tree over the leaves: PLOC (default) or the Karras radix tree + refit (rt_build_options.device_builder = RT_BUILDER_LBVH; also the fallback when
     // a PLOC tree comes out deeper than the traversal stacks allow)
     uint32_t bin_root = 0u;
-    const char *builder_env = std::getenv("RT_DEVICE_BUILDER");
-    bool use_ploc = n_leaves > 1 && !(builder_env && !std::strcmp(builder_env, "lbvh"));
+    bool use_ploc = n_leaves > 1 && d->build.device_builder != RT_BUILDER_LBVH;
     if (use_ploc) {
         Ploc P{};
         // search radius: 8 positions to either side measured best on both bench scenes (S-sponza / S-10M, wide tree collapsed from
         // it: radius 2: 452 / 217 Msamples/s, 4: 495 / 224, 6: 502 / 224, 8: 496 / 244, 16: 464 / 228, 32: 465 / 231; profiles/r03_wide.txt)
         int radius = 8;
-        if (const char *e = std::getenv("RT_PLOC_RADIUS"))
-            radius = std::min(PLOC_MAX_RADIUS, std::max(1, std::atoi(e)));
+        if (d->build.ploc_radius)
+            radius = std::min(PLOC_MAX_RADIUS, std::max(1, (int)d->build.ploc_radius));
         P.radius = radius;
         for (int k = 0; k < 2; ++k) {
             BUILD_TRY(tmp.alloc(&P.ref[k], (size_t)n_leaves));

@@ -178,7 +178,18 @@ struct alignas(16) WfFold { // 32 B: one pending shade() frame, `emission + inne
     float e[3], pad0;
     float s[3], pad1;
 };
-enum { WF_CNT_IN = 0, WF_CNT_TICKET = 2, WF_CNT_SLOTS = 3, WF_CNT_XCD = 32 /* 8 per-partition work tickets, one 128-byte line each */, WF_CNT_XCD_STRIDE = 32, WF_CNT_WORDS = 32 + 8 * 32 };
+enum {
+    WF_CNT_IN = 0, WF_CNT_TICKET = 2, WF_CNT_SLOTS = 3,
+    WF_CNT_XCD = 32 /* 8 per-partition work tickets, one 128-byte line each */, WF_CNT_XCD_STRIDE = 32,
+    WF_CNT_WORDS = WF_CNT_XCD + 8 * WF_CNT_XCD_STRIDE, // queue counters + tickets: cleared at the start of every pass, tickets again per bounce
+    // behind them, never touched by the per-pass / per-bounce clears (round 3 kept these at words 32 and 64, i.e. INSIDE the ticket
+    // lines: wf_advance's ticket reset wiped the census before the host could read it, and the packet policy never engaged)
+    WF_CNT_CENSUS = WF_CNT_WORDS,       // 2 x u64: packet trips, lanes served (wf_extend_packet / wf_extend_wide_packet)
+    WF_CNT_DIAG = WF_CNT_CENSUS + 8,    // 32 x u64: development census words (-DRT_DIAG builds)
+    WF_CNT_ALLOC_WORDS = WF_CNT_DIAG + 64
+};
+static_assert(WF_CNT_XCD + 7 * WF_CNT_XCD_STRIDE < WF_CNT_WORDS && WF_CNT_CENSUS >= WF_CNT_WORDS && WF_CNT_DIAG >= WF_CNT_CENSUS + 4 && (WF_CNT_CENSUS % 2) == 0 && (WF_CNT_DIAG % 2) == 0,
+              "census / diag words must not overlap the ticket lines and must be 8-byte aligned");
 // wf_shade appends a bounce's survivors to WF_STRIPES sub-queues instead of one: a returning atomic on ONE address completes
 // every ~13 ns chip-wide, and one per wave (64 rays) of a 30 M-ray bounce made that single counter the whole kernel's clock
 // (6.3 ms of 6.3 ms; profiles/r02_shade_atomic.txt). Wave slot w of the input queue (positions 64w..64w+63) appends to

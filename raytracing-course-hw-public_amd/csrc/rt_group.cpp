@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -110,8 +111,8 @@ Blocks blocks_of(uint64_t n_pix, uint64_t block, uint32_t r, uint32_t G) {
 
 struct Group {
     std::vector<Replica> ranks;
-    bool use_rccl = true;       // false: RT_GROUP_TRANSPORT=copy (peer copies; rehearsal of the flow where RCCL cannot run)
-    bool self_exchange = false; // RT_GROUP_SELF_EXCHANGE=1: rank 0's own blocks also travel through ncclSend/ncclRecv (N = 1 test)
+    bool use_rccl = true;       // false: RT_BUILD_GROUP_COPY (peer copies; rehearsal of the flow where RCCL cannot run)
+    bool self_exchange = false; // RT_BUILD_GROUP_SELF_EXCHANGE: rank 0's own blocks also travel through ncclSend/ncclRecv (N = 1 test)
     char *recv = nullptr;       // on ranks[0].device: the other ranks' slabs
     size_t recv_cap = 0;
     bool comm_broken = false;   // an exchange failed and the communicators were aborted: later renders report RT_ERR_COMM at once
@@ -191,10 +192,8 @@ int group_create(const rt_scene_desc *desc, const int *devices, int n_devices, G
     if (!desc || !devices || n_devices < 1 || !out)
         return fail(RT_ERR_INVALID_ARG, "rt group: bad argument");
     Group *g = new Group();
-    const char *tr = std::getenv("RT_GROUP_TRANSPORT");
-    g->use_rccl = !(tr && !std::strcmp(tr, "copy"));
-    const char *se = std::getenv("RT_GROUP_SELF_EXCHANGE");
-    g->self_exchange = se && std::atoi(se) != 0;
+    g->use_rccl = !(desc->build_flags & RT_BUILD_GROUP_COPY);
+    g->self_exchange = (desc->build_flags & RT_BUILD_GROUP_SELF_EXCHANGE) != 0;
     g->ranks.resize(n_devices);
     // The host half of rt_create (both reference-topology BVH builds, flattening / wide collapse, shading records, texture pool)
     // is done ONCE; every GPU then uploads the same arrays, one host thread per GPU (C5: 2.4 GB of 288 GB per replica).
@@ -303,6 +302,8 @@ int group_render(Group *g, const rt_params *p, float *fb, uint8_t *rgb8, rt_stat
     std::vector<std::string> errs(G);
     std::vector<rt_stats> sts(G);
     {
+        std::mutex progress_mutex; // rt_params.progress: one call per GPU that finished, serialised
+        uint32_t finished = 0;
         std::vector<std::thread> th;
         for (uint32_t r = 0; r < G; ++r)
             th.emplace_back([&, r] {
@@ -311,11 +312,16 @@ int group_render(Group *g, const rt_params *p, float *fb, uint8_t *rgb8, rt_stat
                 q.shard_count = G;
                 q.shard_block = (uint32_t)block;
                 q.flags |= RT_FLAG_DEVICE_FB;
+                q.progress = nullptr;
                 char *dst = r == 0 ? render0 : g->ranks[r].image;
                 rcs[r] = rgb8 ? rt_render_rgb8(g->ranks[r].scene, &q, reinterpret_cast<uint8_t *>(dst), &sts[r])
                               : rt_render(g->ranks[r].scene, &q, reinterpret_cast<float *>(dst), &sts[r]);
                 if (rcs[r] != RT_OK)
                     errs[r] = rt_last_error();
+                else if (p->progress) {
+                    std::lock_guard<std::mutex> lock(progress_mutex);
+                    p->progress(++finished, G, p->progress_user);
+                }
             });
         for (auto &t : th)
             t.join();
@@ -334,17 +340,22 @@ int group_render(Group *g, const rt_params *p, float *fb, uint8_t *rgb8, rt_stat
     for (uint32_t r = 0; r < G; ++r)
         if (hipError_t e = hipSetDevice(g->ranks[r].device); e != hipSuccess)
             return hip_fail("rt group: hipSetDevice before the exchange", e);
+    // The rank threads work on a COPY of the communicator handles taken here, before any of them starts; a failing rank sets `broken`
+    // and aborts every communicator of that copy once (abort completes the peers' pending operations with an error). Replica::comm is
+    // only written after the join, so no thread ever reads a handle another one is clearing, and a rank that has not posted yet when the
+    // flag goes up skips its RCCL calls instead of posting on an aborted communicator.
+    std::vector<ncclComm_t> comms(G, nullptr);
+    for (uint32_t r = 0; r < G; ++r)
+        comms[r] = g->ranks[r].comm;
+    std::atomic<bool> broken{false};
     std::mutex abort_mutex;
     auto abort_all = [&]() {
         std::lock_guard<std::mutex> lock(abort_mutex);
-        if (g->comm_broken || !rccl().CommAbort)
+        if (broken.exchange(true) || !rccl().CommAbort)
             return;
-        g->comm_broken = true;
-        for (Replica &R : g->ranks)
-            if (R.comm) {
-                (void)rccl().CommAbort(R.comm);
-                R.comm = nullptr;
-            }
+        for (ncclComm_t c : comms)
+            if (c)
+                (void)rccl().CommAbort(c);
     };
     {
         std::vector<std::thread> th;
@@ -370,13 +381,18 @@ int group_render(Group *g, const rt_params *p, float *fb, uint8_t *rgb8, rt_stat
                     }
                     return e == ncclSuccess;
                 };
-                ncclComm_t comm = R.comm; // abort_all() of another rank may clear R.comm: use the copy taken now
+                ncclComm_t comm = comms[r];
                 (void)hip_try(hipSetDevice(R.device), "hipSetDevice"); // verified for every rank just above; the exchange is posted regardless
                 const bool sends = r > 0 || exchange0;
                 const size_t bytes = blk[r].pixels(block) * es;
                 if (sends && bytes)
                     hip_try(copy_blocks(R.slab, r == 0 ? render0 : R.image, true, blk[r], block, r, G, es, R.stream), "pack");
-                if (g->use_rccl) {
+                if (g->use_rccl && broken.load()) {
+                    if (rcs[r] == RT_OK) {
+                        rcs[r] = RT_ERR_COMM;
+                        errs[r] = "the exchange was aborted by another rank's failure";
+                    }
+                } else if (g->use_rccl) {
                     // (a rank that failed above still takes part in the exchange: nobody may be left waiting in ncclRecv)
                     if (r == 0) {
                         nccl_try(N.GroupStart(), "ncclGroupStart");
@@ -397,6 +413,11 @@ int group_render(Group *g, const rt_params *p, float *fb, uint8_t *rgb8, rt_stat
             });
         for (auto &t : th)
             t.join();
+    }
+    if (broken.load()) { // the handles are gone (ncclCommAbort frees them): later renders report RT_ERR_COMM at once
+        g->comm_broken = true;
+        for (Replica &R : g->ranks)
+            R.comm = nullptr;
     }
     for (uint32_t r = 0; r < G; ++r)
         if (rcs[r] != RT_OK)
@@ -439,6 +460,9 @@ int group_render(Group *g, const rt_params *p, float *fb, uint8_t *rgb8, rt_stat
             stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms); // GPUs run concurrently: the slowest one counts
             stats->dominant_ms = std::max(stats->dominant_ms, s.dominant_ms);
             stats->dominant_launches = std::max(stats->dominant_launches, s.dominant_launches);
+            stats->packet_lanes_x100 = std::max(stats->packet_lanes_x100, s.packet_lanes_x100);
+            stats->passes = std::max(stats->passes, s.passes);
+            stats->packet_passes = std::max(stats->packet_passes, s.packet_passes);
         }
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     }

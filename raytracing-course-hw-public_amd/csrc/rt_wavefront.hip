@@ -853,6 +853,7 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
     if (hs && (!hs->counts || !hs->events || hs->n_events < (int)L.ray_depth + 1))
         hs = nullptr;
     uint32_t bound = L.n_paths; // upper bound of the queue entering the bounce about to be launched
+    bool census_pending = false; // the packet census of bounce 0 is on its way to the pinned words (event 0)
     for (uint32_t b = 0; b < L.ray_depth; ++b) {
         L.order = nullptr; // primary rays: dense and coherent as generated
         if (b > 0) {
@@ -860,8 +861,10 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
                 if ((e = hipEventSynchronize(hs->events[b - 1])) != hipSuccess)
                     return e;
                 bound = hs->counts[b - 1];
-                if (b == 2 && packet && packet_census_out)
+                if (census_pending) { // copied before event 1 was recorded: it has landed
                     std::memcpy(packet_census_out, hs->counts + WF_HOST_CENSUS_WORD, 2 * sizeof(unsigned long long));
+                    census_pending = false;
+                }
                 if (bound == 0)
                     break;
             }
@@ -906,11 +909,15 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         else
             WF_LAUNCH((wf_shade<false, false, false>), dim3(shade_blocks), block, 0, stream, S, L);
         WF_LAUNCH(wf_advance, dim3(1), dim3(64), 0, stream, L.counters, L.stripes);
+        if (hs && b == 0 && packet && packet_census_out) { // the packet kernel's census -> pinned words; read at bounce 2, or behind the loop
+            if ((e = hipMemcpyAsync(hs->counts + WF_HOST_CENSUS_WORD, L.packet_census, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+                return e;
+            if ((e = hipEventRecord(hs->events[0], stream)) != hipSuccess)
+                return e;
+            census_pending = true;
+        }
         if (hs && b + 1 < L.ray_depth) { // size of queue b + 1 -> pinned word b + 1 (read by bounce b + 2)
             if ((e = hipMemcpyAsync(hs->counts + b + 1, L.counters + WF_CNT_IN, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
-                return e;
-            if (b == 0 && packet && packet_census_out &&
-                (e = hipMemcpyAsync(hs->counts + WF_HOST_CENSUS_WORD, L.packet_census, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream)) != hipSuccess)
                 return e;
             if ((e = hipEventRecord(hs->events[b + 1], stream)) != hipSuccess)
                 return e;
@@ -920,6 +927,11 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
         L.paths_out = t;
     }
     WF_LAUNCH(wf_fold, dim3(gen_blocks > 0 ? gen_blocks : 1), block, 0, stream, L);
+    if (census_pending) { // ray_depth <= 2 (no bounce 2 to read it at): wait for bounce 0 only; the rest of the pass is queued behind it
+        if ((e = hipEventSynchronize(hs->events[0])) != hipSuccess)
+            return e;
+        std::memcpy(packet_census_out, hs->counts + WF_HOST_CENSUS_WORD, 2 * sizeof(unsigned long long));
+    }
     const int res_blocks = (int)((L.pass_pixels + 255u) / 256u);
     WF_LAUNCH(wf_resolve, dim3(res_blocks > 0 ? res_blocks : 1), block, 0, stream, L, first_pass ? 1 : 0, last_pass ? 1 : 0);
     return hipSuccess;

@@ -100,3 +100,17 @@ def random_rays(scene, n, seed):
     axes = np.eye(3, dtype=np.float32)[rng.integers(0, 3, size=k)] * rng.choice([-1.0, 1.0], size=(k, 1)).astype(np.float32)
     d[:k] = axes
     return np.concatenate([o, d.astype(np.float32)], axis=1).astype(np.float32)
+
+
+SCENE000 = os.path.join(ROOT, "tests", "golden", "txt", "scene-000.txt")  # BASELINE config 1's scene file (a data fixture: the content of the
+                                                                          # reference's sample_data/scene-000.txt)
+
+
+def scene000_box_gltf(rt, sg, out_dir, yfov=1.2):
+    """The triangles of scene-000.txt's BOX (the part of config 1 the reference at HEAD can still render: it has no ELLIPSOID / PLANE and no
+    scene-txt parser) exported as glTF for the reference binary: same 12 triangles and material, camera at the file's position looking down -z,
+    the reference's white environment. Returns (gltf path, arrays of the txt-loaded scene)."""
+    a = rt.parse_scene_txt(SCENE000).arrays()
+    b = dict(a, primitives=[], bg_color=np.ones(3, dtype=np.float32))
+    sc = sg.scene_from_arrays(b, yfov=yfov, rotation=(0.0, 0.0, 0.0, 1.0), face_normals=True)
+    return sg.write_gltf(sc, os.path.join(str(out_dir), "scene000_box.gltf")), a

@@ -124,10 +124,9 @@ def _compare_hits_with_oracle(orc, dev, rays, max_tie_share):
 @pytest.mark.parametrize("case", ["room_5000", "boxes", "tiny_1", "tiny_2", "tiny_5", "tiny_9", "room_1M", "room_5000/lbvh", "boxes/lbvh", "tiny_9/lbvh", "room_1M/lbvh"])
 def test_device_lbvh_invariants_and_closest_hits(gpu, oracle, sg, case, monkeypatch):
     """Both binary builders of rt_bvh_device.hip: PLOC (default; agglomerative clustering along the Morton order) and the Karras
-    radix tree + refit (RT_DEVICE_BUILDER=lbvh, also PLOC's fallback for trees deeper than the traversal stacks)."""
+    radix tree + refit (rt_build_options.device_builder = RT_BUILDER_LBVH, also PLOC's fallback for trees deeper than the traversal stacks)."""
     case, _, builder = case.partition("/")
-    if builder:
-        monkeypatch.setenv("RT_DEVICE_BUILDER", builder)
+    opts = {"device_builder": gpu.RT_BUILDER_LBVH} if builder == "lbvh" else {}
     if case.startswith("room"):
         n = 5000 if case == "room_5000" else 1_000_000
         sc = sg.room_scene(n, seed=3, n_lights=6, n_materials=8, tex_size=8, n_tex_sets=2, offset=0.15 if n == 5000 else 0.05)
@@ -142,7 +141,7 @@ def test_device_lbvh_invariants_and_closest_hits(gpu, oracle, sg, case, monkeypa
                       materials=[sg.Material(color=(0.7, 0.7, 0.7, 1.0), roughness=1.0, metallic=0.0)], textures=[],
                       camera=sg.look_camera((0.0, 0.0, 6.0), yaw_deg=0.0, yfov=0.9))
     orc = oracle.OracleScene(sc)
-    dev = gpu.DeviceScene(sc, device_bvh=True)
+    dev = gpu.DeviceScene(sc, device_bvh=True, **opts)
     try:
         dump = dev.bvh_device_dump(0)
         depth = _check_invariants(dump, sc.positions)

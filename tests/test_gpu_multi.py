@@ -1,7 +1,7 @@
 """Multi-GPU scenes inside the library (rt_create with RT_ALL_DEVICES / rt_create_on; csrc/rt_group.cpp): replicas, interleaved
-blocks, gather on the first GPU. A one-GPU box can run (a) the real RCCL path with G = 1, where RT_GROUP_SELF_EXCHANGE routes
+blocks, gather on the first GPU. A one-GPU box can run (a) the real RCCL path with G = 1, where RT_BUILD_GROUP_SELF_EXCHANGE routes
 the GPU's own blocks through pack -> ncclSend/ncclRecv -> unpack, and (b) G > 1 with repeated ordinals over the peer-copy
-rehearsal transport (RCCL refuses a device twice in one communicator — which is also how RT_ERR_COMM is provoked)."""
+rehearsal transport RT_BUILD_GROUP_COPY (RCCL refuses a device twice in one communicator — which is also how RT_ERR_COMM is provoked)."""
 import numpy as np
 import pytest
 
@@ -25,10 +25,9 @@ W, H, SPP = 72, 50, 4  # 3600 pixels: not a multiple of any block size used belo
 
 def test_all_devices_scene_uses_rccl_and_matches_single_gpu(gpu, scene, single, monkeypatch):
     """rt_create(RT_ALL_DEVICES): communicator created inside rt_create (ncclCommInitAll over every visible GPU); with
-    RT_GROUP_SELF_EXCHANGE the first GPU's own blocks travel through ncclSend/ncclRecv as well, so the RCCL exchange really
+    RT_BUILD_GROUP_SELF_EXCHANGE the first GPU's own blocks travel through ncclSend/ncclRecv as well, so the RCCL exchange really
     runs even with one GPU. Images must equal the single-GPU render bit for bit (float and rgb8)."""
-    monkeypatch.setenv("RT_GROUP_SELF_EXCHANGE", "1")
-    grp = gpu.DeviceScene(scene, device=gpu.RT_ALL_DEVICES)
+    grp = gpu.DeviceScene(scene, device=gpu.RT_ALL_DEVICES, build_flags=gpu.RT_BUILD_GROUP_SELF_EXCHANGE)
     try:
         assert grp.n_devices == gpu.device_count() >= 1 and single.n_devices == 1
         want, wst = single.run_raytracer(W, H, SPP, seed=7, counters=True)
@@ -57,8 +56,7 @@ def test_all_devices_scene_uses_rccl_and_matches_single_gpu(gpu, scene, single, 
 def test_replicated_render_over_rehearsal_transport(gpu, scene, single, monkeypatch, G):
     """G replicas (all on GPU 0) with one host thread each, interleaved blocks, packed slabs gathered on rank 0 and
     de-interleaved: everything of the multi-GPU flow except the RCCL calls themselves (peer copies stand in for them)."""
-    monkeypatch.setenv("RT_GROUP_TRANSPORT", "copy")
-    grp = gpu.DeviceScene(scene, device=[0] * G)
+    grp = gpu.DeviceScene(scene, device=[0] * G, build_flags=gpu.RT_BUILD_GROUP_COPY)
     try:
         assert grp.n_devices == G
         want, _ = single.run_raytracer(W, H, SPP, seed=9)
@@ -80,7 +78,6 @@ def test_group_with_production_build_and_environment_map(gpu, sg, oracle, monkey
     equals one replica's, and the parity-build group equals the ORACLE (the host half of rt_create, incl. the map's texture view, is shared)."""
     import os
 
-    monkeypatch.setenv("RT_GROUP_TRANSPORT", "copy")
     sc = sg.room_scene(700, seed=52, n_lights=0, n_materials=5, tex_size=8, n_tex_sets=2, open_room=True)
     env = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "envmap", "env.png")
     sc.textures = list(sc.textures) + [gpu.image_decode(env)]
@@ -88,9 +85,11 @@ def test_group_with_production_build_and_environment_map(gpu, sg, oracle, monkey
     orc = oracle.OracleScene(sc)
     ofb, _ = orc.run_raytracer(W, H, SPP, seed=4)
     orc.close()
-    grp = gpu.DeviceScene(sc, device=[0, 0, 0])
-    got, _ = grp.run_raytracer(W, H, SPP, seed=4, shard_block=256)
+    grp = gpu.DeviceScene(sc, device=[0, 0, 0], build_flags=gpu.RT_BUILD_GROUP_COPY)
+    seen = []
+    got, _ = grp.run_raytracer(W, H, SPP, seed=4, shard_block=256, progress=lambda done, total: seen.append((done, total)))
     assert np.array_equal(got.view(np.uint32), ofb.view(np.uint32))
+    assert seen == [(1, 3), (2, 3), (3, 3)]  # rt_params.progress on a multi-GPU scene: one report per GPU that finished
     d = np.random.default_rng(8).normal(size=(300, 3))
     d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     one = gpu.DeviceScene(sc)
@@ -98,7 +97,7 @@ def test_group_with_production_build_and_environment_map(gpu, sg, oracle, monkey
     one.close()
     grp.close()
     one = gpu.DeviceScene(sc, device_bvh=True, wide=True)
-    grp = gpu.DeviceScene(sc, device=[0, 0, 0], device_bvh=True, wide=True)
+    grp = gpu.DeviceScene(sc, device=[0, 0, 0], device_bvh=True, wide=True, build_flags=gpu.RT_BUILD_GROUP_COPY)
     want, _ = one.run_raytracer(W, H, SPP, seed=4)
     got, _ = grp.run_raytracer(W, H, SPP, seed=4, shard_block=256)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))  # every replica builds the same tree from the same arrays
@@ -111,7 +110,6 @@ def test_group_with_production_build_and_environment_map(gpu, sg, oracle, monkey
 def test_rccl_refusal_is_reported_as_comm_error(gpu, scene, monkeypatch):
     """The same GPU twice in one communicator: ncclCommInitAll refuses -> RT_ERR_COMM with RCCL's message, no crash,
     no half-built scene left behind."""
-    monkeypatch.delenv("RT_GROUP_TRANSPORT", raising=False)
     with pytest.raises(gpu.RtError) as e:
         gpu.DeviceScene(scene, device=[0, 0])
     assert e.value.code == 7, str(e.value)  # RT_ERR_COMM

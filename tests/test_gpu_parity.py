@@ -14,26 +14,7 @@ from conftest import random_rays
 pytestmark = pytest.mark.gpu
 
 
-class _env:
-    """Set environment variables the library reads per render (RT_WF_PACKET, RT_WF_SORT) for the duration of a with-block."""
-
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        for k, v in self.kv.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+# Tuning travels in rt_params (ABI 4: packet_mode, sort_mode, max_paths), not in the environment: the library reads no variable.
 
 REL_TOL = 1e-5  # north_star: per-pixel radiance within 1e-5 relative
 
@@ -136,9 +117,9 @@ def test_render_device_rng_matches_oracle(pairs, gpu, name):
     dev, orc, _ = pairs[name]
     W, H, SPP = 48, 40, 6
     ofb, ost = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=1234)
-    for pkt in ("0", "1"): # primary rays per lane (wf_extend) / as packets (wf_extend_packet)
-        with _env(RT_WF_PACKET=pkt):
-            gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=1234, counters=True)
+    for pkt in (gpu.RT_PACKET_OFF, gpu.RT_PACKET_ON):  # primary rays per lane (wf_extend) / as packets (wf_extend_packet)
+        gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=1234, counters=True, packet_mode=pkt)
+        assert gst["packet_passes"] == (gst["passes"] if pkt == gpu.RT_PACKET_ON else 0) and gst["passes"] == 1
         assert np.isfinite(gfb).all()
         err = _rel_err(gfb, ofb)
         assert err.max() <= REL_TOL, f"max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
@@ -153,20 +134,14 @@ def test_queue_shapes_match_oracle(pairs, gpu, shape):
     """wf_shade appends to 64 sub-queues whose regions are whole wave slots; the next bounce maps the dense ray index back to
     a slot (with a sort from 4096 rays up, directly below). Path counts below one wave, not multiples of 64, exactly at and
     across the 4096-ray sort threshold (a queue that shrinks below it between bounces) all give the oracle's framebuffer
-    bit for bit, with every ray-order key (RT_WF_SORT 1..5; 5 is the default) and with sorting off."""
+    bit for bit, with every ray-order key (rt_params.sort_mode, RT_SORT_*; OCTANT_CELL_CONE is what AUTO picks) and with sorting off."""
     dev, orc, _ = pairs["room_manylights"]
     W, H, SPP = shape
     ofb, ost = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=99)
-    for sort in ("5", "4", "3", "2", "1", "0") if shape == (96, 50, 2) else ("5", "0"):
-        old = os.environ.get("RT_WF_SORT")
-        os.environ["RT_WF_SORT"] = sort
-        try:
-            gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=99, counters=True)
-        finally:
-            if old is None:
-                os.environ.pop("RT_WF_SORT", None)
-            else:
-                os.environ["RT_WF_SORT"] = old
+    all_keys = (gpu.RT_SORT_OCTANT_CELL_CONE, gpu.RT_SORT_CELL_OCTANT_CONE, gpu.RT_SORT_OCTANT_CELL, gpu.RT_SORT_COARSE_CELL_DIR, gpu.RT_SORT_CELL_OCTANT, gpu.RT_SORT_OFF,
+                gpu.RT_SORT_AUTO)
+    for sort in all_keys if shape == (96, 50, 2) else (gpu.RT_SORT_OCTANT_CELL_CONE, gpu.RT_SORT_OFF):
+        gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=99, counters=True, sort_mode=sort)
         assert np.array_equal(gfb.view(np.uint32), ofb.view(np.uint32)), (shape, sort)
         assert gst["samples"] == ost["samples"] == W * H * SPP and gst["casts"] == ost["casts"] and gst["shaded_hits"] == ost["shaded_hits"]
 
@@ -187,7 +162,8 @@ def test_render_reference_rng_matches_oracle(pairs, gpu, name):
 def test_wavefront_equals_megakernel_and_is_pass_invariant(pairs, gpu, monkeypatch):
     """The wavefront pipeline (default for RT_RNG_DEVICE) and the persistent megakernel (RT_FLAG_MEGAKERNEL) are two
     schedules of the same per-path arithmetic: framebuffers and event counters must be identical, and splitting the
-    render into more passes (sample ranges x pixel tiles, RT_WF_MAX_PATHS) must not change a bit."""
+    render into more passes (sample ranges x pixel tiles, rt_params.max_paths) must not change a bit; the progress callback
+    (rt_params.progress; the reference prints one line per finished span, raytracer.h:647) reports every pass once, in order."""
     dev, orc, _ = pairs["room_textured"]
     W, H, SPP = 56, 44, 7
     ofb, _ = orc.run_raytracer(W, H, SPP, seed=21)
@@ -198,13 +174,48 @@ def test_wavefront_equals_megakernel_and_is_pass_invariant(pairs, gpu, monkeypat
     for k in ("samples", "casts", "nodes_visited", "box_tests", "tri_tests", "shaded_hits", "light_queries", "light_tri_tests", "texel_fetches"):
         assert mst[k] == wst[k], k
     for max_paths in (5000, 1500, 1024):  # several sample passes; < W*H -> pixel tiles as well
-        monkeypatch.setenv("RT_WF_MAX_PATHS", str(max_paths))
-        fb, _ = dev.run_raytracer(W, H, SPP, seed=21)
+        seen = []
+        fb, st = dev.run_raytracer(W, H, SPP, seed=21, max_paths=max_paths, progress=lambda done, total: seen.append((done, total)))
         assert np.array_equal(fb.view(np.uint32), ofb.view(np.uint32)), max_paths
+        assert st["passes"] > 1 and seen == [(k + 1, st["passes"]) for k in range(st["passes"])], (max_paths, st["passes"], seen)
         sh = np.zeros_like(fb)
         for r in range(3):
-            dev.run_raytracer(W, H, SPP, seed=21, shard_index=r, shard_count=3, shard_block=256, out=sh)
+            dev.run_raytracer(W, H, SPP, seed=21, shard_index=r, shard_count=3, shard_block=256, out=sh, max_paths=max_paths)
         assert np.array_equal(sh.view(np.uint32), ofb.view(np.uint32)), max_paths
+
+
+def test_packet_census_reaches_the_host_and_drives_the_policy(pairs, gpu, oracle, sg):
+    """wf_extend_packet counts trips and lanes served; the host reads the two words one bounce late and drops the packet kernel for a
+    configuration whose packets fall apart (rt_params.packet_min_lanes). Round 3 kept the census inside the XCD ticket lines, where
+    wf_advance's ticket reset wiped it before the read-back: rt_stats said 0 and the policy never engaged. Here: the census
+    arrives (also with ray_depth <= 2, which has no bounce 2 to read it at), a threshold of 64 lanes switches packets off after the first
+    pass, and none of it changes a bit of the image."""
+    dev, orc, _ = pairs["room_textured"]
+    W, H = 64, 48
+    ofb, _ = orc.run_raytracer(W, H, 64, seed=3)
+    fb, st = dev.run_raytracer(W, H, 64, seed=3)  # one pass of 64 SPP: RT_PACKET_AUTO starts with packets (>= 16 samples per pixel and pass)
+    assert st["passes"] == 1 and st["packet_passes"] == 1 and 100 <= st["packet_lanes_x100"] <= 6400, st
+    assert np.array_equal(fb.view(np.uint32), ofb.view(np.uint32))
+    fb, st = dev.run_raytracer(W, H, 64, seed=3, max_paths=W * H * 16, packet_min_lanes=64.0)  # 4 passes; no packet serves 64 lanes on every trip
+    assert st["passes"] == 4 and st["packet_passes"] == 1 and 100 <= st["packet_lanes_x100"] < 6400, st
+    assert np.array_equal(fb.view(np.uint32), ofb.view(np.uint32))
+    fb, st = dev.run_raytracer(W, H, 64, seed=3, max_paths=W * H * 16, packet_min_lanes=1.0)  # a threshold every packet meets: packets stay
+    assert st["passes"] == 4 and st["packet_passes"] == 4, st
+    assert np.array_equal(fb.view(np.uint32), ofb.view(np.uint32))
+    fb, st = dev.run_raytracer(W, H, 64, seed=3, max_paths=W * H * 16, packet_mode=gpu.RT_PACKET_OFF)
+    assert st["passes"] == 4 and st["packet_passes"] == 0 and st["packet_lanes_x100"] != 0  # (the last census read stays on record)
+    for depth in (1, 2):
+        sc = sg.room_scene(300, seed=5, n_lights=3, n_materials=5, tex_size=8, n_tex_sets=2, alpha_fraction=0.3)
+        sc.ray_depth = depth
+        d2, o2 = gpu.DeviceScene(sc), oracle.OracleScene(sc)
+        try:
+            want, _ = o2.run_raytracer(40, 36, 32, seed=2)
+            got, st = d2.run_raytracer(40, 36, 32, seed=2, max_paths=40 * 36 * 16, packet_min_lanes=64.0)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), depth
+            assert st["passes"] == 2 and st["packet_passes"] == 1 and st["packet_lanes_x100"] != 0, (depth, st)
+        finally:
+            d2.close()
+            o2.close()
 
 
 def test_full_size_bench_scene_parity(gpu, oracle, sg):
@@ -239,17 +250,7 @@ def test_full_size_bench_scene_parity(gpu, oracle, sg):
     for r in range(4):
         dev.run_raytracer(W, H, 8, seed=7, shard_index=r, shard_count=4, shard_block=8 * W, out=sh)
     assert np.array_equal(sh.view(np.uint32), a.view(np.uint32))
-    old = {k: os.environ.get(k) for k in ("RT_WF_SORT", "RT_WF_MAX_PATHS")}
-    try:
-        os.environ["RT_WF_SORT"] = "0"
-        os.environ["RT_WF_MAX_PATHS"] = str(3_000_000)
-        b, _ = dev.run_raytracer(W, H, 8, seed=7)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    b, _ = dev.run_raytracer(W, H, 8, seed=7, sort_mode=gpu.RT_SORT_OFF, max_paths=3_000_000)
     assert np.array_equal(b.view(np.uint32), a.view(np.uint32))
     assert np.isfinite(a).all() and a.mean() > 1e-4
     # a second and a third scene in the same process, their FIRST render being a sorted wavefront render: the workspace
@@ -272,9 +273,8 @@ def _cmp_render(gpu, oracle, sc, W=40, H=36, SPP=5, seed=3):
         # the wavefront pipeline with primary rays through wf_extend (per lane) and through wf_extend_packet (64-ray packets),
         # then the persistent megakernel: one image, one set of event counts
         o, os_ = orc.run_raytracer(W, H, SPP, seed=seed)
-        for kw, pkt in (({}, "0"), ({}, "1"), ({"megakernel": True}, None)):
-            with _env(RT_WF_PACKET=pkt):
-                g, gs = dev.run_raytracer(W, H, SPP, seed=seed, counters=True, **kw)
+        for kw, pkt in (({}, gpu.RT_PACKET_OFF), ({}, gpu.RT_PACKET_ON), ({"megakernel": True}, gpu.RT_PACKET_AUTO)):
+            g, gs = dev.run_raytracer(W, H, SPP, seed=seed, counters=True, packet_mode=pkt, **kw)
             assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), (kw, pkt)
             for k in ("casts", "nodes_visited", "box_tests", "tri_tests", "shaded_hits", "texel_fetches", "light_tri_tests"):
                 assert gs[k] == os_[k], (k, kw, pkt)

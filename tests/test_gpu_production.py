@@ -262,7 +262,7 @@ def test_wide_render_matches_oracle(wide_pairs, gpu, name):
 
 def test_device_collapse_equals_host_collapse_of_the_same_tree(gpu, sg, monkeypatch):
     """RT_BUILD_WIDE on a device-built tree runs the collapse ON THE DEVICE (dynamic program inside the refit kernel, level-by-level
-    emission). The same LBVH collapsed by wide_build.cpp on the host (RT_WIDE_HOST_COLLAPSE=1) must give the same tree up to
+    emission). The same LBVH collapsed by wide_build.cpp on the host (RT_BUILD_WIDE_HOST_COLLAPSE) must give the same tree up to
     float-vs-double ties in the cost comparisons: same triangles, (almost) the same node count, depth and leaf-size histogram."""
     from test_wide_build import decode, walk_and_check
 
@@ -271,12 +271,10 @@ def test_device_collapse_equals_host_collapse_of_the_same_tree(gpu, sg, monkeypa
     d1 = dev.bvh_wide_dump()
     t1 = dev.build_times()
     dev.close()
-    monkeypatch.setenv("RT_WIDE_HOST_COLLAPSE", "1")
-    dev = gpu.DeviceScene(sc, wide=True, device_bvh=True)
+    dev = gpu.DeviceScene(sc, wide=True, device_bvh=True, build_flags=gpu.RT_BUILD_WIDE_HOST_COLLAPSE)
     d2 = dev.bvh_wide_dump()
     t2 = dev.build_times()
     dev.close()
-    monkeypatch.delenv("RT_WIDE_HOST_COLLAPSE")
     depth1, hist1 = walk_and_check(d1["nodes"], d1["tris"][:, 9].copy(), sc.positions)
     depth2, hist2 = walk_and_check(d2["nodes"], d2["tris"][:, 9].copy(), sc.positions)
     n1, n2 = len(d1["nodes"]), len(d2["nodes"])

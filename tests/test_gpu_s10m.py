@@ -96,15 +96,9 @@ def test_s10m_full_size_parity_and_properties(gpu, oracle, sg):
     assert np.array_equal(a.view(np.uint32), m.view(np.uint32)), "wavefront pipeline != persistent megakernel"
     for k in COUNTERS:
         assert ast[k] == mst[k], k
-    oldp = os.environ.get("RT_WF_PACKET")
-    try:
-        os.environ["RT_WF_PACKET"] = "1"  # primary rays as 64-ray packets (wf_extend_packet) even at 2 SPP: incoherent packets, same hits
-        pk, pst = dev.run_raytracer(W, H, 2, seed=11, counters=True)
-    finally:
-        if oldp is None:
-            os.environ.pop("RT_WF_PACKET", None)
-        else:
-            os.environ["RT_WF_PACKET"] = oldp
+    # primary rays as 64-ray packets (wf_extend_packet) even at 2 SPP: incoherent packets, same hits
+    pk, pst = dev.run_raytracer(W, H, 2, seed=11, counters=True, packet_mode=gpu.RT_PACKET_ON)
+    assert pst["packet_passes"] == pst["passes"] >= 1 and 100 <= pst["packet_lanes_x100"] <= 6400  # the census reaches the host (r03: wiped by the ticket reset)
     assert np.array_equal(pk.view(np.uint32), a.view(np.uint32)), "packet traversal of the primary rays != per-lane traversal"
     for k in COUNTERS:
         assert pst[k] == ast[k], k
@@ -112,15 +106,7 @@ def test_s10m_full_size_parity_and_properties(gpu, oracle, sg):
     for r in range(8):
         dev.run_raytracer(W, H, 2, seed=11, shard_index=r, shard_count=8, shard_block=8 * W, out=sh)
     assert np.array_equal(sh.view(np.uint32), a.view(np.uint32)), "union of 8 shards != single render"
-    old = os.environ.get("RT_WF_MAX_PATHS")
-    try:
-        os.environ["RT_WF_MAX_PATHS"] = str(3_000_000)  # several pixel tiles x sample passes
-        b, _ = dev.run_raytracer(W, H, 2, seed=11)
-    finally:
-        if old is None:
-            os.environ.pop("RT_WF_MAX_PATHS", None)
-        else:
-            os.environ["RT_WF_MAX_PATHS"] = old
+    b, _ = dev.run_raytracer(W, H, 2, seed=11, max_paths=3_000_000)  # several pixel tiles x sample passes
     assert np.array_equal(b.view(np.uint32), a.view(np.uint32))
     img, _ = dev.run_raytracer_rgb8(W, H, 2, seed=11)
     assert np.array_equal(img, gpu.tonemap(a))

@@ -125,6 +125,62 @@ def test_config2_primitives_only_512x512(gpu, oracle, tmp_path):
         orc.close()
 
 
+def test_config1_scene000_through_the_hip_path(gpu, sg, oracle, tmp_path):
+    """BASELINE config 1: sample_data/scene-000.txt (committed as tests/golden/txt/scene-000.txt: ELLIPSOID + PLANE + BOX), 256x256, 4 SPP,
+    through librt_amd.so. (a) the CLI, `run.sh scene-000.txt 256 256 4 out.ppm`, writes the oracle's PPM in both RNG modes; (b) device-RNG
+    framebuffer and event counters equal the oracle's, in both schedules, sharded and through the device film; (c) the part of the scene
+    the reference at HEAD can still render, the BOX's triangles exported as glTF, renders in reference-RNG mode to the bytes the UNMODIFIED
+    reference binary produced (tests/golden/txt_scene000_box_64x48x4.ppm, tests/golden/make_scene000_golden.py)."""
+    from conftest import SCENE000, scene000_box_gltf
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    W = H = 256
+    SPP = 4
+    dev, orc, ls = _pair(gpu, oracle, SCENE000)
+    try:
+        a = ls.arrays()
+        assert a["positions"].shape[0] == 12 and [p["kind"] for p in a["primitives"]] == [1, 2]
+        # (a) the CLI
+        for mode, seed in (("reference", 0), ("device", 17)):
+            out = tmp_path / f"c1_{mode}.ppm"
+            subprocess.check_call([os.path.join(root, "run.sh"), SCENE000, str(W), str(H), str(SPP), str(out)], env=dict(os.environ, RT_RNG_MODE=mode, RT_SEED=str(seed), RT_DEVICE="0"))
+            ofb, _ = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_REFERENCE if mode == "reference" else gpu.RT_RNG_DEVICE, seed=seed)
+            assert np.array_equal(oracle.read_ppm(str(out)), oracle.tonemap(ofb)), mode
+        # (b) the library
+        ofb, ost = orc.run_raytracer(W, H, SPP, seed=17)
+        for kw in ({}, {"megakernel": True}, {"packet_mode": gpu.RT_PACKET_ON}):
+            gfb, gst = dev.run_raytracer(W, H, SPP, seed=17, counters=True, **kw)
+            assert np.array_equal(gfb.view(np.uint32), ofb.view(np.uint32)), (kw, int((gfb != ofb).any(axis=2).sum()))
+            for k in COUNTERS:
+                assert gst[k] == ost[k], (k, kw)
+        img, _ = dev.run_raytracer_rgb8(W, H, SPP, seed=17)
+        assert np.array_equal(img, oracle.tonemap(ofb))
+        sh = np.zeros_like(ofb)
+        for r in range(4):
+            dev.run_raytracer(W, H, SPP, seed=17, shard_index=r, shard_count=4, shard_block=8 * W, out=sh)
+        assert np.array_equal(sh.view(np.uint32), ofb.view(np.uint32))
+        rfb, _ = dev.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_REFERENCE)
+        orf, _ = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_REFERENCE)
+        assert np.array_equal(rfb.view(np.uint32), orf.view(np.uint32))
+        rays = _rays(6, 20000, -6, 6)
+        gp, gb = dev.cast_rays(rays)
+        op, ob = orc.cast_rays(rays)
+        assert np.array_equal(gp, op) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+        assert (gp == 12).sum() > 500 and (gp == 13).sum() > 500 and (gp < 12).sum() > 20  # all three primitive kinds win rays
+    finally:
+        dev.close()
+        orc.close()
+    # (c) the BOX against the reference binary's bytes
+    gltf, _ = scene000_box_gltf(gpu, sg, tmp_path)
+    box = gpu.DeviceScene(gpu.parse_gltf_scene(gltf, 64 / 48))
+    try:
+        img, _ = box.run_raytracer_rgb8(64, 48, 4, rng_mode=gpu.RT_RNG_REFERENCE)
+        gold = oracle.read_ppm(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "txt_scene000_box_64x48x4.ppm"))
+        assert np.array_equal(img, gold)
+    finally:
+        box.close()
+
+
 def test_cli_renders_a_scene_txt(gpu, oracle, tmp_path):
     """run.sh <scene.txt> <W> <H> <SPP> <out.ppm>: the reference's CLI shape with the scene-txt front end behind it."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(rt):
     assert "rt_render" in names and "rt_create" in names and "rt_gltf_load" in names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ but not exported by librt_amd.so"
-    assert lib.rt_abi_version() == 3
+    assert lib.rt_abi_version() == 4
 
 
 def test_ctypes_prototypes_cover_the_headers(rt):
@@ -45,15 +45,34 @@ def test_struct_layouts_match_the_c_headers(rt, tmp_path):
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "rt_abi.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
         "sizeof(rt_camera),sizeof(rt_texture_desc),sizeof(rt_material_desc),sizeof(rt_scene_desc),sizeof(rt_params),sizeof(rt_stats),"
-        "offsetof(rt_scene_desc,camera),offsetof(rt_params,seed),sizeof(rt_primitive_desc),offsetof(rt_scene_desc,primitives),offsetof(rt_primitive_desc,rotation));return 0;}\n"
+        "offsetof(rt_scene_desc,camera),offsetof(rt_params,seed),sizeof(rt_primitive_desc),offsetof(rt_scene_desc,primitives),offsetof(rt_primitive_desc,rotation));"
+        'printf("%zu %zu %zu %zu %zu %zu %zu\\n",sizeof(rt_build_options),offsetof(rt_scene_desc,build),offsetof(rt_build_options,wide_order),offsetof(rt_params,sort_mode),'
+        "offsetof(rt_params,max_paths),offsetof(rt_params,progress_user),offsetof(rt_stats,packet_passes));return 0;}\n"
     )
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(abi.RtCamera), ctypes.sizeof(abi.RtTextureDesc), ctypes.sizeof(abi.RtMaterialDesc), ctypes.sizeof(abi.RtSceneDesc),
             ctypes.sizeof(abi.RtParams), ctypes.sizeof(abi.RtStats), abi.RtSceneDesc.camera.offset, abi.RtParams.seed.offset,
-            ctypes.sizeof(abi.RtPrimitiveDesc), abi.RtSceneDesc.primitives.offset, abi.RtPrimitiveDesc.rotation.offset]
+            ctypes.sizeof(abi.RtPrimitiveDesc), abi.RtSceneDesc.primitives.offset, abi.RtPrimitiveDesc.rotation.offset,
+            # ABI 4: build options, tuning fields, progress callback, packet census
+            ctypes.sizeof(abi.RtBuildOptions), abi.RtSceneDesc.build.offset, abi.RtBuildOptions.wide_order.offset, abi.RtParams.sort_mode.offset,
+            abi.RtParams.max_paths.offset, abi.RtParams.progress_user.offset, abi.RtStats.packet_passes.offset]
     assert got == want
+
+
+def test_library_reads_no_environment_variable():
+    """ABI 4: every knob is a field of rt_scene_desc / rt_params (the reference's are constexpr, config.h:7-47). getenv appears
+    only in the CLI (csrc/host/main.cpp), which translates variables into fields; bench.py does the same on the Python side."""
+    csrc = os.path.join(ROOT, "raytracing-course-hw-public_amd", "csrc")
+    hits = []
+    for d, _, files in os.walk(csrc):
+        for f in files:
+            if f.endswith((".cpp", ".hip", ".h")) and not (d.endswith("host") and f == "main.cpp"):
+                text = open(os.path.join(d, f)).read()
+                if re.search(r"\bgetenv\b|\bsecure_getenv\b|\benviron\b", text):
+                    hits.append(os.path.relpath(os.path.join(d, f), csrc))
+    assert hits == [], hits
 
 
 def test_sub_queue_regions_tile_the_queue(tmp_path):

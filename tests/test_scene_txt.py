@@ -105,6 +105,50 @@ def test_box_and_triangle_primitives_are_pinned_through_gltf(rt, sg, oracle, tmp
         assert np.array_equal(oracle.tonemap(fb), ref)
 
 
+def test_config1_fixture_and_its_box_pinned_to_the_reference_binary(rt, sg, oracle, tmp_path):
+    """BASELINE config 1 = sample_data/scene-000.txt (ELLIPSOID, PLANE, BOX; 256x256, 4 SPP). The committed fixture is that file; the part
+    the reference at HEAD can still render — the BOX's 12 triangles — comes back bit-identical through the glTF loader and the oracle renders
+    it to the bytes the UNMODIFIED reference binary produced (tests/golden/make_scene000_golden.py). The GPU half: tests/test_gpu_txt.py."""
+    from conftest import SCENE000, scene000_box_gltf
+
+    ref_file = "/root/reference/sample_data/scene-000.txt"
+    if os.path.exists(ref_file):
+        assert open(ref_file, "rb").read() == open(SCENE000, "rb").read()
+    gltf, a = scene000_box_gltf(rt, sg, tmp_path)
+    assert a["positions"].shape[0] == 12 and [p["kind"] for p in a["primitives"]] == [1, 2]  # BOX -> 12 triangles; ELLIPSOID, PLANE
+    ls = rt.parse_gltf_scene(gltf, W / H)
+    g = ls.arrays()
+    for k in ("positions", "normals", "texcoords", "tangents"):
+        assert np.array_equal(a[k].view(np.uint32), g[k].view(np.uint32)), k
+    for k in ("color", "emission", "roughness", "metallic", "ior"):
+        assert np.array_equal(np.asarray(a["materials"][int(a["material_ids"][0])][k]), np.asarray(g["materials"][int(g["material_ids"][0])][k])), k
+    fb, _ = oracle.OracleScene(ls).run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_REFERENCE)
+    out = tmp_path / "o.ppm"
+    rt.write_ppm(str(out), rt.tonemap(fb))
+    assert out.read_bytes() == open(os.path.join(GOLD, f"txt_scene000_box_{W}x{H}x{SPP}.ppm"), "rb").read()
+    if oracle.have_reference_build():
+        assert np.array_equal(oracle.tonemap(fb), oracle.run_reference(gltf, W, H, SPP, str(tmp_path / "ref.ppm")))
+    # the whole file at the configuration's size on the CPU path (reference RNG, as config 1 says): finite, deterministic, all three kinds visible
+    orc = oracle.OracleScene(rt.parse_scene_txt(SCENE000))
+    fb1, st = orc.run_raytracer(256, 256, 4, rng_mode=rt.RT_RNG_REFERENCE, threads=1)
+    fb2, _ = orc.run_raytracer(256, 256, 4, rng_mode=rt.RT_RNG_REFERENCE, threads=4)
+    assert st["samples"] == 256 * 256 * 4 and np.isfinite(fb1).all() and np.array_equal(fb1.view(np.uint32), fb2.view(np.uint32))
+    prim, _ = orc.cast_rays(_primary_rays(a["camera"], 256, 256))
+    assert set(np.unique(prim).tolist()) >= {12, 13} and (prim < 12).sum() > 100  # ELLIPSOID (12), PLANE (13) and BOX triangles all seen
+    orc.close()
+
+
+def _primary_rays(cam, W_, H_):
+    """Pixel-centre rays of gen_ray (raytracer.h:516-525) for a loaded camera, float32."""
+    x, y = np.meshgrid(np.arange(W_, dtype=np.float64) + 0.5, np.arange(H_, dtype=np.float64) + 0.5)
+    tx = np.tan(float(cam["fov_x"]) / 2)
+    ty = tx * H_ / W_
+    d = ((2 * x / W_ - 1) * tx)[..., None] * cam["right"].astype(np.float64) - ((2 * y / H_ - 1) * ty)[..., None] * cam["up"].astype(np.float64) + cam["forward"].astype(np.float64)
+    d /= np.linalg.norm(d, axis=2, keepdims=True)
+    o = np.broadcast_to(cam["position"].astype(np.float64), d.shape)
+    return np.concatenate([o, d], axis=2).reshape(-1, 6).astype(np.float32)
+
+
 def test_analytic_primitives_self_consistency(rt, oracle):
     """ELLIPSOID / PLANE ("parity unpinned"): closest hits reported through the oracle's probe agree with an independent
     double-precision evaluation of the same geometry, and the front / back conventions hold."""
