@@ -33,8 +33,9 @@ N > 1, two ways to launch, same sharding (interleaved 8-row tiles, block b -> GP
   * python bench.py --gpus N                                                   (WORLD_SIZE unset) ONE process: the library's own
     multi-GPU scene (rt_create_on: a replica per GPU + ncclCommInitAll, csrc/rt_group.cpp) renders and gathers.
 Either way the line says n_gpus = N only if N GPUs really took part; fewer visible devices or a rank-count mismatch exit non-zero.
---scaling weak: SPP = 64 x N (per-GPU work fixed). --scaling strong: BASELINE config 4 exactly, 1000x1000 at 1000 SPP in all.
-auto (default): strong at N = 8 (that IS config 4), weak otherwise.
+--scaling weak (default, = auto): SPP = 64 x N (per-GPU work fixed), at every N: the driver's 1 -> 8 curve is one regime. --scaling strong:
+BASELINE config 4 exactly, 1000x1000 at 1000 SPP in all, as the headline. Whatever the headline, a sponza run also carries `config4`: one
+timed step of config 4 (1000 SPP in all over the N GPUs taking part) measured after the headline, so a strong-scaling curve exists beside it.
 
 The "roofline" object (dominant kernel: the closest-hit kernel, wf_extend / wf_extend_packet / wf_extend_wide):
   achieved / frac / traffic   HBM-SIDE bytes per launch (rocprofv3 PMC passes kept under profiles/, FETCH_SIZE doubled + WRITE_SIZE
@@ -203,7 +204,7 @@ def resolve_spp(scaling: str, gpus: int, wl: dict, explicit_spp: int):
     if explicit_spp > 0:
         return explicit_spp, ("strong" if scaling == "strong" else "weak")
     if scaling == "auto":
-        scaling = "strong" if gpus == 8 else "weak"
+        scaling = "weak"  # ONE regime for the whole 1 -> 8 curve the driver assembles; config 4 (strong, 1000 SPP) rides along as `config4` at every N
     if scaling == "strong":
         return CONFIG4_SPP, "strong"  # BASELINE config 4: 1000 SPP in all, whatever N
     return wl["spp_per_gpu"] * gpus, "weak"
@@ -218,7 +219,7 @@ def make_scene(rt, wl, n_tri, tex_size, aspect):
 class Runner:
     """One device scene (one traversal mode) of one workload: timed steps + the roofline record of its closest-hit kernel."""
 
-    def __init__(self, rt, torch, dist, scene, wl_name, mode, W, H, spp, launcher, rank, world, n_gpus, local_rank, backend, film, full_size, device_bvh=False):
+    def __init__(self, rt, torch, dist, scene, wl_name, mode, W, H, spp, launcher, rank, world, n_gpus, local_rank, backend, film, full_size, device_bvh=False, all_gather=False):
         """`full_size`: True (the workload's own geometry at its per-GPU SPP: the configuration the committed profiles describe),
         "config4" (same geometry, 1000 SPP in all) or False (custom sizes)."""
         self.rt, self.torch, self.dist = rt, torch, dist
@@ -239,7 +240,7 @@ class Runner:
         self.fb = torch.zeros(self.n_pix * 3, dtype=torch.float32, device=self.device)
         self.img = torch.zeros(self.n_pix * 3, dtype=torch.uint8, device=self.device) if film else self.fb
         self.gather_device = self.device if backend == "nccl" else torch.device("cpu")
-        self.gather = sharding.FramebufferGather(self.n_pix, self.block, rank, world, self.gather_device, dtype=self.img.dtype)
+        self.gather = sharding.FramebufferGather(self.n_pix, self.block, rank, world, self.gather_device, dtype=self.img.dtype, all_gather=all_gather)
         self.my_pixels = sharding.shard_pixels(self.n_pix, self.block, rank, world)
         torch.cuda.synchronize()  # RT_FLAG_DEVICE_FB precondition (rt_abi.h): the zero-fills above ran on torch's stream
 
@@ -331,16 +332,28 @@ class Runner:
         stream_peak, stream_src = measured_stream_peak()
         kernel = ("wf_extend_wide<false> (8-wide quantised BVH, every bounce)" if self.m["wide"] else
                   f"wf_extend<false, {'true' if self.m['gbest'] else 'false'}> (closest hit; primary rays through wf_extend_packet while its packets stay coherent)")
+        frac_x1 = round(traffic_x1 / launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic_x1 else None
+        frac_x2 = round(hbm_rate / HBM_PEAK_GBS, 4) if hbm_rate else None
         return {
             "bound": "hbm",  # the roof the contract prices this path against (no dense contraction -> no MFMA roof)
-            "achieved": round(hbm_rate, 2) if hbm_rate else None,
+            # the contract's formula: ALGORITHMIC bytes per launch / live launch time / peak. Cache hits are not subtracted, so on
+            # a cache-resident working set it exceeds 1; the HBM-side fractions are right below, named
+            "achieved": round(algorithmic, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": round(hbm_rate / HBM_PEAK_GBS, 4) if hbm_rate else None,
-            "achieved_is": "HBM-side bytes per closest-hit launch (committed PMC profile of the same sources: 2 x FETCH_SIZE + WRITE_SIZE) / live launch time; null when no matching profile exists (see traffic_source)",
+            "frac": round(algorithmic / HBM_PEAK_GBS, 4),
+            "frac_is": "frac = frac_algorithmic (SURVEY 8d: box tests x 24 + node visits x 16 + triangle tests x 36 bytes, cache hits included) / launch time / 8 TB/s: work done, > 1 when caches serve it. "
+                       "HBM utilisation proper: frac_hbm_counters_x1 (FETCH_SIZE as counted: what this kernel's <= 64-byte gathers cost, tools/ubench/gather64.hip) and frac_hbm_counters_x2 (FETCH_SIZE doubled, the guide's gfx950 rule for streaming reads: an upper bound here)",
+            "frac_algorithmic": round(algorithmic / HBM_PEAK_GBS, 4),
+            "frac_hbm_counters_x1": frac_x1,
+            "frac_hbm_counters_x2": frac_x2,
+            "valu_busy": (pmc or {}).get("valu_busy"),
+            "lanes_per_valu": (pmc or {}).get("lanes_per_valu"),
+            "l1_pending_stall_frac": (pmc or {}).get("l1_pending_stall_frac"),
             "traffic": traffic,
+            "traffic_fetch_x1": traffic_x1,
             "traffic_source": traffic_source,
-            "frac_fetch_x1": round(traffic_x1 / launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic_x1 else None,
+            "frac_fetch_x1": frac_x1,
             "fetch_size_multiplier": "x2 is MI355X_MICROARCH.md's prescription (a streaming request moves a 128-B line); this kernel's gathers are <= 64-B records, for which "
                                      "tools/ubench/gather64.hip measures ONE request per record (profiles/r02_gather64_calibration.txt): x1 (frac_fetch_x1) is what the workload's own calibration supports, x2 an upper bound",
             "algorithmic_GBps": round(algorithmic, 2),
@@ -371,6 +384,35 @@ class Runner:
                 "tri_tests_per_cast": round(cst["tri_tests"] / max(1, cst["casts"]), 1),
             },
         }
+
+    def float_image(self):
+        """One more render of the timed configuration through rt_render: the linear float3 framebuffer as a device tensor (a copy)."""
+        self.dev.run_raytracer(self.W, self.H, self.spp, seed=SEED, device_fb=self.fb.data_ptr(), global_best=self.m["gbest"], **self.shard_kw())
+        return self.fb.clone()
+
+    def compare_with(self, parity_fb):
+        """The production contract at the depth the number is quoted at: this mode's full image against the parity-mode GPU image of the same
+        run (itself pinned to the oracle by tests/test_gpu_parity.py). Pixels are compared bit for bit and against the 1e-5 relative band."""
+        torch = self.torch
+        mine = self.float_image().view(-1, 3)
+        ref = parity_fb.view(-1, 3)
+        bits = (mine.view(torch.int32) != ref.view(torch.int32)).any(dim=1)
+        rel = ((mine - ref).abs() / ref.abs().clamp_min(1e-6)).max(dim=1).values
+        beyond = rel > 1e-5
+        worst = [int(i) for i in torch.nonzero(beyond).flatten()[:8].tolist()]
+        return {"pixels": int(ref.shape[0]), "spp": self.spp, "pixels_differing_from_parity": int(bits.sum().item()), "pixels_beyond_1e-5_relative": int(beyond.sum().item()),
+                "max_relative_difference": float(rel.max().item()), "first_pixels_beyond": worst,
+                "compared": "linear float3 framebuffer of this mode vs the parity-mode framebuffer of the same invocation (same seed, same samples), on the device",
+                "expected": "0 unless a path met an exact tie between two triangles, or a hit the reference's own near-local pruning skips (bvh.h:216-223: a far child whose rounded entry distance is >= the near hit "
+                            "although a triangle inside rounds closer); tests/test_gpu_production.py and tests/test_gpu_s10m.py assert the same count at full size"}
+
+    def packet_record(self):
+        """What the primary-ray packet policy did in the last timed step (rt_stats: passes, packet passes, the kernel's own census)."""
+        st = getattr(self, "last_stats", None) or {}
+        lanes = st.get("packet_lanes_x100", 0) / 100.0
+        return {"passes": st.get("passes"), "packet_passes": st.get("packet_passes"), "lanes_served_per_trip": lanes if lanes else None,
+                "threshold": self.tuning.get("packet_min_lanes") or (20.0 if self.m["wide"] else 33.0), "mode": {None: "auto", 1: "off", 2: "on"}[self.tuning.get("packet_mode")],
+                "policy": "primary rays go through the 64-ray packet kernel while its census (lanes served per trip, read back one bounce late) stays at or above the threshold for this image size / samples per pass"}
 
     def close(self):
         self.dev.close()
@@ -408,7 +450,9 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: sponza, with S-10M as extra_workloads.s10m on one GPU")
-    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"], help="strong = BASELINE config 4 (1000 SPP in all); auto: strong at 8 GPUs, weak otherwise")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"], help="weak (= auto): 64 SPP per GPU at every N; strong = BASELINE config 4 (1000 SPP in all) as the headline")
+    ap.add_argument("--no-config4", action="store_true", help="skip the extra config-4 record (one 1000-SPP step after the headline)")
+    ap.add_argument("--gather", default="gather", choices=["gather", "allgather"], help="torchrun flow: dist.gather to rank 0, or all_gather_into_tensor")
     ap.add_argument("--mode", default="parity", choices=sorted(MODES), help="traversal mode of the HEADLINE value (default parity; the others are reported under 'production')")
     ap.add_argument("--bvh", default="reference", choices=["reference", "device"],
                     help="binary builder: reference = host build in the reference's exact topology (the parity tree); device = built on the GPU (rt_bvh_device.hip: PLOC, or the radix-tree LBVH with RT_DEVICE_BUILDER=lbvh). "
@@ -461,21 +505,33 @@ def main() -> None:
     t0 = time.time()
     scene = make_scene(rt, wl, n_tri, tex_size, W / H)
     t_gen = time.time() - t0
-    common = dict(launcher=launcher, rank=rank, world=world, n_gpus=args.gpus, local_rank=local_rank, backend=args.backend, film=film, device_bvh=args.bvh == "device")
+    common = dict(launcher=launcher, rank=rank, world=world, n_gpus=args.gpus, local_rank=local_rank, backend=args.backend, film=film, device_bvh=args.bvh == "device", all_gather=args.gather == "allgather")
     run = Runner(rt, torch, dist, scene, wl_name, args.mode, W, H, spp, full_size=full_size, **common)
     if launcher == "group" and run.ranks_formed != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the library formed {run.ranks_formed} rank(s)")
     value = run.timed(args.steps, args.warmup)
     roofline = run.roofline()
+    roofline["packet"] = run.packet_record()
     elapsed = run.elapsed
+    single = args.gpus == 1 and rank == 0
+    extras = single and not args.no_extras
+    parity_fb = run.float_image() if (extras and args.mode == "parity") else None
+    config4 = None
+    if wl_name == "sponza" and full_geometry and scaling != "strong" and not args.no_config4 and args.mode == "parity":
+        # BASELINE config 4 beside the weak-scaling headline: 1000 SPP in all over the GPUs taking part, one timed step (10^9 samples)
+        keep = (run.spp, run.elapsed, run.steps, run.kernel_ms, run.dom_ms, run.dom_launches, run.last_stats)
+        run.spp = CONFIG4_SPP
+        v4 = run.timed(1, 0)
+        config4 = {"value": round(v4, 3), "unit": "Msamples/s", "scaling": "strong", "spp": CONFIG4_SPP, "steps": 1, "warmup": 0, "ms_per_step": round(run.elapsed * 1e3, 3), "n_gpus": args.gpus,
+                   "passes": run.last_stats.get("passes"), "packet_passes": run.last_stats.get("packet_passes"),
+                   "config": f"BASELINE config 4: {wl['label']} {W}x{H}, {CONFIG4_SPP} SPP in all, sharded over {args.gpus} GPU(s), traversal {args.mode}"}
+        run.spp, run.elapsed, run.steps, run.kernel_ms, run.dom_ms, run.dom_launches, run.last_stats = keep
     setup = {"scene_generation": round(t_gen, 2), "rt_create_bvh_upload": round(run.t_create, 2), "scene_bvh_build": round(run.build_times["build_ms"] / 1e3, 4)}
     run.close()
 
-    single = args.gpus == 1 and rank == 0
-    extras = single and not args.no_extras
     x_steps, x_warm = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
 
-    def production_records(scene_, wl_name_, W_, H_, spp_, full_, parity_value, skip, steps_, warm_):
+    def production_records(scene_, wl_name_, W_, H_, spp_, full_, parity_value, skip, steps_, warm_, parity_fb_):
         out = {}
         for mode in ("global", "wide"):
             if mode == skip:
@@ -485,18 +541,21 @@ def main() -> None:
             r = Runner(rt, torch, dist, scene_, wl_name_, mode, W_, H_, spp_, full_size=full_, **kw)
             v = r.timed(steps_, warm_)
             rf = r.roofline()
+            rf["packet"] = r.packet_record()
             out[mode] = {"traversal": MODES[mode]["text"] + (", binary tree (PLOC) and collapse built on the device" if mode == "wide" else ""), "workload_id": r.workload_id, "value": round(v, 3), "unit": "Msamples/s", "steps": steps_, "warmup": warm_,
                          "ms_per_step": round(r.elapsed / steps_ * 1e3, 3), "vs_parity": round(v / parity_value, 3) if parity_value else None,
-                         "rt_create_s": round(r.t_create, 2), "build_ms": {k: round(v, 2) for k, v in r.build_times.items()}, "roofline": rf}
+                         "rt_create_s": round(r.t_create, 2), "build_ms": {k: round(v, 2) for k, v in r.build_times.items()}, "roofline": rf,
+                         "image_vs_parity": r.compare_with(parity_fb_) if parity_fb_ is not None else None}
             r.close()
-        out["parity_of_these_modes"] = ("tests/test_gpu_production.py, against the CPU oracle: closest-hit t bit-equal on every ray (5 fixtures, S-sponza 60 000 rays, S-10M 100 000 rays), "
+        out["parity_of_these_modes"] = ("image_vs_parity: the full image at the quoted SPP against the parity-mode image, counted in this run; tests/test_gpu_production.py, against the CPU oracle: closest-hit t bit-equal on every ray (5 fixtures, S-sponza 60 000 rays, S-10M 100 000 rays), "
                                         "index differences only on exact ties, the S-sponza 1000x1000x1 SPP framebuffer bit-identical to the oracle's; the wide tree may find a hit "
                                         "1 ulp CLOSER than the reference where the reference's own pruning skips it (coplanar overlapping triangles): counted there")
         return out
 
     production = None
     if extras and args.mode == "parity":
-        production = production_records(scene, wl_name, W, H, spp, full_size, value, None, x_steps, x_warm)
+        production = production_records(scene, wl_name, W, H, spp, full_size, value, None, x_steps, x_warm, parity_fb)
+        del parity_fb
 
     cpu_baseline = None
     if single and not args.no_cpu_baseline:
@@ -513,6 +572,8 @@ def main() -> None:
         xr = Runner(rt, torch, dist, xscene, "s10m", "parity", xw["width"], xw["height"], xw["spp_per_gpu"], full_size=True, **common)
         xv = xr.timed(xs, xk)
         xrf = xr.roofline()
+        xrf["packet"] = xr.packet_record()
+        x_parity_fb = xr.float_image()
         rec = {"metric": xw["metric"], "value": round(xv, 3), "unit": "Msamples/s", "n_gpus": 1, "steps": xs, "warmup": xk, "ms_per_step": round(xr.elapsed / xs * 1e3, 3),
                "config": {"workload": f"S-10M synthetic (BVH cache stress, BASELINE config 5's scene): {xw['triangles']}+28 triangles, 16x3 {xw['tex_size']}^2 RGBA8 textures, "
                                       f"{xw['width']}x{xw['height']}, {xw['spp_per_gpu']} SPP, ray_depth 8, device RNG", "workload_id": "s10m", "traversal": MODES["parity"]["text"]},
@@ -520,7 +581,7 @@ def main() -> None:
                "cpu_baseline_skipped": "the oracle's reference-topology build of 10^7 triangles takes ~25 s on this box before a single sample: python bench.py --workload s10m times it",
                "setup_s": {"scene_generation": round(xt_gen, 2), "rt_create_bvh_upload": round(xr.t_create, 2), "scene_bvh_build": round(xr.build_times["build_ms"] / 1e3, 4)}}
         xr.close()
-        rec["production"] = production_records(xscene, "s10m", xw["width"], xw["height"], xw["spp_per_gpu"], True, xv, "global", xs, xk)
+        rec["production"] = production_records(xscene, "s10m", xw["width"], xw["height"], xw["spp_per_gpu"], True, xv, "global", xs, xk, x_parity_fb)
         extra_workloads = {"s10m": rec}
 
     if rank == 0:
@@ -560,6 +621,7 @@ def main() -> None:
                 "bvh": "reference topology, host build" if args.bvh == "reference" else "built on the device (PLOC; identical closest hits, different topology and counters)",
             },
             "roofline": roofline,
+            "config4": config4,
             "cpu_baseline": cpu_baseline,
             "production": production,
             "extra_workloads": extra_workloads,

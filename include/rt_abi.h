@@ -323,6 +323,13 @@ enum {
 };
 int rt_cast_rays_ex(rt_scene *scene, const float *rays, uint32_t n, uint32_t mode, uint32_t *prim_out, float *bct_out, rt_stats *stats);
 
+/* Intersection-info probe: the closest hit of each ray as rt_cast_rays reports it, plus the two normals to_intersection_info
+ * (bvh.h:80-121) hands to shade(): `normal` (the geometric normal, flipped to face the ray: bvh.h:86-87, 118) and `shading_normal`
+ * (smooth normal through the normal map, flipped likewise: bvh.h:94-108, 119). For an analytic primitive both are its unit normal
+ * facing the ray (rt_primspec.h). 3 floats each per ray, zeros for a miss; either output may be NULL. Lets the tests pin normals
+ * against an independent evaluation (tests/test_gpu_txt.py: float64 closed forms for ELLIPSOID / PLANE). */
+int rt_surface_normals(rt_scene *scene, const float *rays, uint32_t n, uint32_t *prim_out, float *t_out, float *normal_out, float *shading_normal_out);
+
 /* Light-pdf probe: bvh_mix_dist::pdf (raytracer.h:363-375) for n (origin, dir) pairs. */
 int rt_light_pdf(rt_scene *scene, const float *rays, uint32_t n, float *pdf_out);
 

@@ -323,6 +323,18 @@ class DeviceScene:
         _check(lib().rt_cast_rays_ex(self._h, fptr(rays), n, int(mode), u32ptr(prim), fptr(bct), C.byref(st)))
         return prim, bct, st.as_dict()
 
+    def surface_normals(self, rays: np.ndarray):
+        """rt_surface_normals: closest hit + the normals to_intersection_info (bvh.h:80-121) hands to shade().
+        Returns (prim, t, normal (n,3), shading_normal (n,3))."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        prim = np.zeros(n, dtype=np.uint32)
+        t = np.zeros(n, dtype=np.float32)
+        nn = np.zeros((n, 3), dtype=np.float32)
+        sn = np.zeros((n, 3), dtype=np.float32)
+        _check(lib().rt_surface_normals(self._h, fptr(rays), n, u32ptr(prim), fptr(t), fptr(nn), fptr(sn)))
+        return prim, t, nn, sn
+
     def light_pdf(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
         n = rays.shape[0]

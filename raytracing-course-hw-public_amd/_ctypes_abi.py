@@ -183,6 +183,7 @@ ABI_PROTOTYPES = {
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(RtParams), C.c_void_p, C.POINTER(RtStats)]),
     "rt_cast_rays": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, c_u32_p, c_float_p]),
     "rt_cast_rays_ex": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, C.c_uint32, c_u32_p, c_float_p, C.POINTER(RtStats)]),
+    "rt_surface_normals": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, c_u32_p, c_float_p, c_float_p, c_float_p]),
     "rt_light_pdf": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, c_float_p]),
     "rt_bg_at": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, c_float_p]),
     "rt_bvh_wide_dump": (C.c_int, [C.c_void_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),

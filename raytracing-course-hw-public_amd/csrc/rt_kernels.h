@@ -41,6 +41,7 @@ struct EventPool {
 // rt_kernels.hip: persistent megakernel (reference-RNG parity mode; cross-check of the wavefront path) + probes
 hipError_t launch_render(const DevScene &S, const RenderLaunch &L, bool stats, int blocks, hipStream_t stream);
 hipError_t launch_cast(const DevScene &S, const float *rays, uint32_t n, uint32_t *prim, float *bct, hipStream_t stream);
+hipError_t launch_surface_normals(const DevScene &S, const float *rays, uint32_t n, uint32_t *prim, float *t, float *normal, float *shading, hipStream_t stream);
 hipError_t launch_light_pdf(const DevScene &S, const float *rays, uint32_t n, float *pdf, hipStream_t stream);
 hipError_t launch_bg_at(const DevScene &S, const float *dirs, uint32_t n, float *rgb, hipStream_t stream);
 // rt_wavefront.hip: one pass (pixel tile x sample range) of the wavefront pipeline, stream-ordered

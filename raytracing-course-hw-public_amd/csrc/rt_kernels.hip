@@ -247,6 +247,40 @@ __global__ __launch_bounds__(256) void cast_kernel(const DevScene S, const float
     }
 }
 
+// rt_surface_normals: cast_kernel's closest hit, then the normals make_surf (to_intersection_info, bvh.h:80-121) gives shade()
+__global__ __launch_bounds__(256) void surface_normals_kernel(const DevScene S, const float *rays, uint32_t n, uint32_t *prim_out, float *t_out, float *normal_out, float *shading_out) {
+    __shared__ uint32_t s_stack[STACK_LDS_DWORDS];
+    __shared__ float s_lin[256];
+    __shared__ float s_gam[256];
+    s_lin[threadIdx.x] = S.lut_linear[threadIdx.x];
+    s_gam[threadIdx.x] = S.lut_gamma[threadIdx.x];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    RT_DECLARE_STACK(stk, LDS_DEPTH, s_stack);
+    LaneStats<false> st;
+    Trav T;
+    trav_init(T, S.scene, ld3(rays + 6ull * i), ld3(rays + 6ull * i + 3));
+    while (T.cur != T_DONE)
+        trav_step<false>(T, S.scene, stk, EPS, st);
+    Hit h = T.best;
+    if (S.n_prims)
+        prims_closest(S, T.o, T.d, h);
+    V3 nn = mk(0.f, 0.f, 0.f), sn = nn;
+    if (h.k != RT_NONE) {
+        const Surf s = make_surf<false>(S, h, T.o, T.d, s_lin, s_gam, st);
+        nn = s.normal;
+        sn = s.shading_normal;
+    }
+    prim_out[i] = h.k == RT_NONE ? RT_NONE : (h.k & RT_PRIM_FLAG) ? S.n_triangles + (h.k & ~RT_PRIM_FLAG) : S.scene.tris[h.k].prim;
+    t_out[i] = h.k == RT_NONE ? 0.0f : h.t;
+    if (normal_out)
+        normal_out[3ull * i] = nn.x, normal_out[3ull * i + 1] = nn.y, normal_out[3ull * i + 2] = nn.z;
+    if (shading_out)
+        shading_out[3ull * i] = sn.x, shading_out[3ull * i + 1] = sn.y, shading_out[3ull * i + 2] = sn.z;
+}
+
 __global__ __launch_bounds__(256) void light_pdf_kernel(const DevScene S, const float *rays, uint32_t n, float *pdf_out) {
     __shared__ uint32_t s_stack[STACK_LDS_DWORDS];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,6 +336,12 @@ hipError_t launch_cast(const DevScene &S, const float *rays, uint32_t n, uint32_
     if (n == 0)
         return hipSuccess;
     return RT_LAUNCH_CHECKED(cast_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, rays, n, prim, bct);
+}
+
+hipError_t launch_surface_normals(const DevScene &S, const float *rays, uint32_t n, uint32_t *prim, float *t, float *normal, float *shading, hipStream_t stream) {
+    if (n == 0)
+        return hipSuccess;
+    return RT_LAUNCH_CHECKED(surface_normals_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, rays, n, prim, t, normal, shading);
 }
 
 hipError_t launch_light_pdf(const DevScene &S, const float *rays, uint32_t n, float *pdf, hipStream_t stream) {

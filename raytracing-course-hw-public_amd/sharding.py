@@ -32,7 +32,8 @@ class FramebufferGather:
     """Reusable buffers + the gather itself. `fb` is the rank's full-size flat framebuffer (n_pix*3 floats) in which
     only this rank's blocks are valid (that is what rt_render writes with shard_count = world)."""
 
-    def __init__(self, n_pix: int, block: int, rank: int, world: int, device: torch.device, dtype: torch.dtype = torch.float32):
+    def __init__(self, n_pix: int, block: int, rank: int, world: int, device: torch.device, dtype: torch.dtype = torch.float32, all_gather: bool = False):
+        """`all_gather`: exchange with all_gather_into_tensor instead of gather (same bytes per link on a ring; every rank ends up with the slabs)."""
         self.n_pix, self.block, self.rank, self.world = n_pix, block, rank, world
         self.nb = n_blocks(n_pix, block)
         self.max_blocks = (self.nb + world - 1) // world
@@ -40,9 +41,7 @@ class FramebufferGather:
         self.slab = torch.zeros(self.max_blocks * block * 3, dtype=dtype, device=device)
         self.gathered = [torch.empty_like(self.slab) for _ in range(world)] if (world > 1 and rank == 0) else None
         self.full = torch.zeros(self.nb * block * 3, dtype=dtype, device=device) if rank == 0 else None
-        import os
-
-        self.use_all_gather = os.environ.get("RT_GATHER", "gather") == "allgather"
+        self.use_all_gather = bool(all_gather)
         self.all_slabs = None
 
     def gather(self, fb: torch.Tensor) -> Optional[torch.Tensor]:
@@ -52,7 +51,7 @@ class FramebufferGather:
         self.padded[: self.n_pix * 3] = fb
         mine = self.padded.view(self.nb, self.block * 3)[self.rank :: self.world]
         self.slab[: mine.numel()] = mine.reshape(-1)
-        if self.use_all_gather:  # RT_GATHER=allgather: same bytes per link on a ring, every rank ends up with the slabs
+        if self.use_all_gather:
             if self.all_slabs is None:
                 self.all_slabs = torch.empty(self.world * self.slab.numel(), dtype=self.slab.dtype, device=self.slab.device)
             dist.all_gather_into_tensor(self.all_slabs, self.slab)

@@ -116,3 +116,69 @@ def test_rccl_refusal_is_reported_as_comm_error(gpu, scene, monkeypatch):
     with pytest.raises(gpu.RtError) as e:
         gpu.DeviceScene(scene, device=[0, 99])
     assert e.value.code in (1, 3)  # invalid ordinal: reported by the replica's rt_create
+
+
+# ------------------------------------------------------------------------------------------------ one process per GPU (bench.py's torchrun flow)
+def _hip_rank(rank, world, port, out_path):
+    """One rank of the torch.distributed flow: renders ITS interleaved blocks with librt_amd.so (all ranks share GPU 0 here), then the
+    same sharding.FramebufferGather bench.py uses assembles the image on rank 0 — over gloo, staged through the host, because RCCL refuses
+    one GPU twice; on a multi-GPU node the identical code runs with backend nccl on device tensors."""
+    import importlib
+    import os
+    import sys
+
+    import torch  # before librt_amd.so: one HIP runtime for both
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rt = importlib.import_module("raytracing-course-hw-public_amd")
+    sharding = importlib.import_module("raytracing-course-hw-public_amd.sharding")
+    sc = rt.scenegen.room_scene(900, seed=51, n_lights=5, n_materials=6, tex_size=16, n_tex_sets=2, alpha_fraction=0.2)
+    dev = rt.DeviceScene(sc, device=0)
+    n_pix, block = W * H, 256
+    fb = torch.full((n_pix * 3,), -1.0, dtype=torch.float32, device="cuda:0")  # radiance is never negative: -1 marks 'not written'
+    img = torch.zeros(n_pix * 3, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()  # RT_FLAG_DEVICE_FB precondition: the fills ran on torch's stream
+    dev.run_raytracer(W, H, SPP, seed=7, shard_index=rank, shard_count=world, shard_block=block, device_fb=fb.data_ptr())
+    dev.run_raytracer_rgb8(W, H, SPP, seed=7, shard_index=rank, shard_count=world, shard_block=block, device_rgb8=img.data_ptr())
+    host = fb.cpu()
+    mine = torch.zeros(n_pix, dtype=torch.bool)
+    for b0 in range(rank * block, n_pix, world * block):
+        mine[b0 : b0 + block] = True
+    written = (host.view(-1, 3) != -1.0).any(dim=1)
+    assert not written[~mine].any() and written[mine].all()  # exactly this rank's blocks were rendered
+    full = sharding.FramebufferGather(n_pix, block, rank, world, torch.device("cpu")).gather(host)
+    full8 = sharding.FramebufferGather(n_pix, block, rank, world, torch.device("cpu"), dtype=torch.uint8).gather(img.cpu())
+    if rank == 0:
+        np.save(out_path, full.numpy().reshape(H, W, 3))
+        np.save(out_path + ".rgb8.npy", full8.numpy().reshape(H, W, 3))
+    dev.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_torch_distributed_ranks_render_with_the_hip_library(gpu, scene, single, oracle, tmp_path, world):
+    """bench.py --gpus N under torch.distributed.run, rehearsed on one GPU: `world` processes, each a rank with its own DeviceScene on GPU 0
+    rendering its blocks through the C-ABI, gathered with sharding.FramebufferGather (tests/test_sharding_gloo.py runs the same flow with the
+    CPU oracle standing in for the GPU). The assembled float image and the rgb8 image equal the single-GPU render AND the oracle bit for bit.
+    Still unverified on hardware: the same exchange over RCCL between different GPUs (no multi-GPU node is available to a round's own runs)."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    port = 29600 + (os.getpid() + world) % 2000
+    out = str(tmp_path / "full.npy")
+    mp.spawn(_hip_rank, args=(world, port, out), nprocs=world, join=True)
+    got = np.load(out)
+    want, _ = single.run_raytracer(W, H, SPP, seed=7)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    orc = oracle.OracleScene(scene)
+    ofb, _ = orc.run_raytracer(W, H, SPP, seed=7)
+    orc.close()
+    assert np.array_equal(got.view(np.uint32), ofb.view(np.uint32))
+    assert np.array_equal(np.load(out + ".rgb8.npy"), gpu.tonemap(want))

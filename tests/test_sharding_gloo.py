@@ -17,7 +17,6 @@ W, H, SPP, BLOCK = 40, 37, 2, 256  # 1480 pixels: 6 blocks, the last one partial
 
 
 def _worker(rank, world, port, out_path, mode):
-    os.environ["RT_GATHER"] = mode
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -32,7 +31,7 @@ def _worker(rank, world, port, out_path, mode):
     n_pix = W * H
     fb = np.full((H, W, 3), -1.0, dtype=np.float32)  # radiance is never negative: -1 marks 'not written'
     orc.run_raytracer(W, H, SPP, seed=77, shard_index=rank, shard_count=world, shard_block=BLOCK, out=fb, threads=2)
-    g = sharding.FramebufferGather(n_pix, BLOCK, rank, world, torch.device("cpu"))
+    g = sharding.FramebufferGather(n_pix, BLOCK, rank, world, torch.device("cpu"), all_gather=mode == "allgather")
     full = g.gather(torch.from_numpy(fb.reshape(-1)))
     # exactly this rank's interleaved blocks were written
     mine = np.zeros(n_pix, dtype=bool)
@@ -43,7 +42,7 @@ def _worker(rank, world, port, out_path, mode):
     assert not written[~mine].any() and written[mine].all()
     # the rgb8 flow bench.py runs by default (film applied per rank, uint8 slabs gathered: a 4x smaller message)
     img = oracle.tonemap(fb)
-    g8 = sharding.FramebufferGather(n_pix, BLOCK, rank, world, torch.device("cpu"), dtype=torch.uint8)
+    g8 = sharding.FramebufferGather(n_pix, BLOCK, rank, world, torch.device("cpu"), dtype=torch.uint8, all_gather=mode == "allgather")
     full8 = g8.gather(torch.from_numpy(img.reshape(-1)))
     if rank == 0:
         np.save(out_path, full.numpy().reshape(H, W, 3))
