@@ -197,7 +197,8 @@ enum {
     RT_SORT_COARSE_CELL_DIR = 3,  /* 16^3 cell, 9-bit direction code */
     RT_SORT_OCTANT_CELL = 4,      /* octant, 64^3 cell */
     RT_SORT_CELL_OCTANT_CONE = 5, /* cell, octant, sub-cone (24 bits) */
-    RT_SORT_OCTANT_CELL_CONE = 6  /* octant, cell, sub-cone: what AUTO picks */
+    RT_SORT_OCTANT_CELL_CONE = 6, /* octant, cell, sub-cone: what AUTO picks */
+    RT_SORT_OCTANT_FINE_CELL_CONE = 7 /* octant, 128^3 cell, sub-cone (27 bits) */
 };
 /* Primary rays as 64-ray packets (wf_extend_packet / wf_extend_wide_packet) */
 enum {

@@ -32,6 +32,7 @@ _PROTOS = {
     "rto_destroy": (None, [C.c_void_p]),
     "rto_render": (C.c_int, [C.c_void_p, C.POINTER(_abi.RtParams), _abi.c_float_p, C.POINTER(_abi.RtStats), C.c_int]),
     "rto_cast_rays": (C.c_int, [C.c_void_p, _abi.c_float_p, C.c_uint32, _abi.c_u32_p, _abi.c_float_p]),
+    "rto_trace_pixel": (C.c_int, [C.c_void_p, C.POINTER(_abi.RtParams), C.c_uint32, C.c_uint32, _abi.c_float_p, _abi.c_u32_p, _abi.c_u32_p]),
     "rto_light_pdf": (C.c_int, [C.c_void_p, _abi.c_float_p, C.c_uint32, _abi.c_float_p]),
     "rto_bg_at": (C.c_int, [C.c_void_p, _abi.c_float_p, C.c_uint32, _abi.c_float_p]),
     "rto_bg_uv": (None, [_abi.c_float_p, C.c_uint32, C.c_int, _abi.c_float_p]),
@@ -111,6 +112,17 @@ class OracleScene:
         bct = np.zeros((n, 3), dtype=np.float32)
         _check(lib().rto_cast_rays(self._h, _abi.fptr(rays), n, _abi.u32ptr(prim), _abi.fptr(bct)))
         return prim, bct
+
+    def trace_pixel(self, width, height, samples, pixel, seed=0):
+        """The rays the samples of one pixel cast (device-RNG mode), in cast order: (rays (n, 6) float32, sample index per ray)."""
+        p = _abi.RtParams(width, height, samples, _abi.RT_RNG_DEVICE, seed, 0, 1, 0, 0)
+        n = C.c_uint32()
+        cap = samples * 64
+        rays = np.zeros((cap, 6), dtype=np.float32)
+        smp = np.zeros(cap, dtype=np.uint32)
+        _check(lib().rto_trace_pixel(self._h, C.byref(p), int(pixel), cap, _abi.fptr(rays), _abi.u32ptr(smp), C.byref(n)))
+        assert n.value <= cap
+        return rays[: n.value].copy(), smp[: n.value].copy()
 
     def light_pdf(self, rays):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)

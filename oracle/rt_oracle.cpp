@@ -537,6 +537,7 @@ template <class R> struct Integrator {
     Counters c;
     unsigned width, height, samples;
     float tan_x, tan_y;
+    std::vector<float> *ray_log = nullptr; // rto_trace_pixel: every ray cast_ray sees, 6 floats each, in cast order
 
     Integrator(const rto_scene &s, unsigned w, unsigned h, unsigned spp) : sc(s), width(w), height(h), samples(spp) {
         // raytracer.h:531-535 + Camera::fov_y scene.h:69-71 (float overloads)
@@ -700,6 +701,8 @@ template <class R> struct Integrator {
     // replacement of update_intersection (bvh.h:132)
     bool cast_ray(const Ray &ray, IntersectionInfo &out) {
         c.casts++;
+        if (ray_log)
+            ray_log->insert(ray_log->end(), {ray.start.x, ray.start.y, ray.start.z, ray.dir.x, ray.dir.y, ray.dir.z});
         Hit h;
         if (sc.scene_bvh.root != NO_CHILD)
             h = sc.scene_bvh.intersect_ray(ray, EPS, sc.scene_bvh.root, c);
@@ -968,6 +971,35 @@ int rto_render(rto_scene *s, const rt_params *p, float *fb, rt_stats *stats, int
         stats->total_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         stats->kernel_ms = stats->total_ms;
     }
+    return RT_OK;
+}
+
+// Test aid: the rays one pixel's samples cast, in cast order (device-RNG mode: every (pixel, sample) has its own stream). Lets a test that finds a
+// pixel where a production image differs from the parity image put THAT path's rays through both scenes' closest-hit probes and name the cause
+// (an exact tie, or a hit the reference's near-local pruning skips). rays_out: 6 floats per ray, sample_out: the sample each ray belongs to.
+int rto_trace_pixel(rto_scene *s, const rt_params *p, uint32_t pixel, uint32_t cap, float *rays_out, uint32_t *sample_out, uint32_t *n_out) {
+    if (!s || !p || !n_out || p->rng_mode != RT_RNG_DEVICE || (uint64_t)pixel >= (uint64_t)p->width * p->height) {
+        g_err = "rto_trace_pixel: bad argument (device-RNG mode only)";
+        return RT_ERR_INVALID_ARG;
+    }
+    Integrator<RngXoshiro> it(*s, p->width, p->height, p->samples);
+    std::vector<float> log;
+    it.ray_log = &log;
+    uint32_t n = 0;
+    for (unsigned smp = 0; smp < p->samples; ++smp) {
+        rt_xoshiro_seed(&it.rng.g, p->seed, pixel, smp);
+        const size_t before = log.size();
+        Ray ray = it.gen_ray((int)(pixel % p->width), (int)(pixel / p->width));
+        (void)it.trace_ray(ray, s->ray_depth);
+        for (size_t k = before; k < log.size(); k += 6, ++n)
+            if (n < cap) {
+                if (rays_out)
+                    std::memcpy(rays_out + 6 * (size_t)n, log.data() + k, 24);
+                if (sample_out)
+                    sample_out[n] = smp;
+            }
+    }
+    *n_out = n;
     return RT_OK;
 }
 

@@ -42,6 +42,7 @@ from ._ctypes_abi import (
     RT_SORT_OCTANT_CELL,
     RT_SORT_CELL_OCTANT_CONE,
     RT_SORT_OCTANT_CELL_CONE,
+    RT_SORT_OCTANT_FINE_CELL_CONE,
     RT_PACKET_AUTO,
     RT_PACKET_OFF,
     RT_PACKET_ON,

@@ -21,7 +21,7 @@ RT_BUILD_GROUP_COPY = 16
 RT_BUILD_GROUP_SELF_EXCHANGE = 32
 RT_BUILDER_PLOC, RT_BUILDER_LBVH = 0, 1
 RT_WIDE_ORDER_DEFAULT, RT_WIDE_ORDER_LEVEL, RT_WIDE_ORDER_DFS, RT_WIDE_ORDER_TREELET = range(4)
-RT_SORT_AUTO, RT_SORT_OFF, RT_SORT_CELL_OCTANT, RT_SORT_COARSE_CELL_DIR, RT_SORT_OCTANT_CELL, RT_SORT_CELL_OCTANT_CONE, RT_SORT_OCTANT_CELL_CONE = range(7)
+RT_SORT_AUTO, RT_SORT_OFF, RT_SORT_CELL_OCTANT, RT_SORT_COARSE_CELL_DIR, RT_SORT_OCTANT_CELL, RT_SORT_CELL_OCTANT_CONE, RT_SORT_OCTANT_CELL_CONE, RT_SORT_OCTANT_FINE_CELL_CONE = range(8)
 RT_PACKET_AUTO, RT_PACKET_OFF, RT_PACKET_ON = range(3)
 RT_TEX_NONE = -1
 RT_RNG_DEVICE = 0

@@ -99,7 +99,11 @@ static_assert(sizeof(DevTexture) == 32, "DevTexture must be 32 bytes");
 //   * the triangles of the node's leaf slots are consecutive DevTri records from tri_base: bit 3s + j of tri_mask says that leaf
 //     slot s holds a j-th triangle (at most 3 per slot), and that triangle is record tri_base + popcount(tri_mask below the bit).
 // An empty slot has an inverted box (qlo 255, qhi 0) that no ray hits.
+#ifdef RT_WIDE_NODE_PAD128 /* experiment: one node per 128-byte line (never straddles); same fields */
+struct alignas(128) WideNode {
+#else
 struct alignas(16) WideNode {
+#endif
     float p[3];           // grid origin = the node box's lower corner
     uint8_t e[3];         // biased exponents: cell size on axis a = 2^(e[a] - 127)
     uint8_t imask;        // bit s: slot s is an inner node
@@ -110,7 +114,9 @@ struct alignas(16) WideNode {
     uint8_t qlo[3][8];    // [axis][slot]
     uint8_t qhi[3][8];
 };
+#ifndef RT_WIDE_NODE_PAD128
 static_assert(sizeof(WideNode) == 80, "WideNode must be 80 bytes");
+#endif
 #define RT_WIDE_MAX_LEAF_TRIS 3u
 
 struct DevBvh {

@@ -649,6 +649,12 @@ __global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLa
             const float ax = __builtin_fabsf(r0.w), ay = __builtin_fabsf(r1.x), az = __builtin_fabsf(r1.y);
             const uint32_t sub = (ax > ay ? 1u : 0u) | (ay > az ? 2u : 0u) | (ax > az ? 4u : 0u);
             key = (oct << 21) | (morton << 3) | sub;
+        } else if (L.sort_mode == 6) { // octant, 128^3 cell, sub-cone (27 bits): a finer origin cell for trees far beyond the caches
+            const uint32_t fx7 = (uint32_t)fminf(fmaxf(fx * 128.0f, 0.0f), 127.0f), fy7 = (uint32_t)fminf(fmaxf(fy * 128.0f, 0.0f), 127.0f), fz7 = (uint32_t)fminf(fmaxf(fz * 128.0f, 0.0f), 127.0f);
+            const uint32_t m21 = (morton << 3) | (fx7 & 1u) | ((fy7 & 1u) << 1) | ((fz7 & 1u) << 2); // the 64^3 code refined by one more bit per axis
+            const float ax = __builtin_fabsf(r0.w), ay = __builtin_fabsf(r1.x), az = __builtin_fabsf(r1.y);
+            const uint32_t sub = (ax > ay ? 1u : 0u) | (ay > az ? 2u : 0u) | (ax > az ? 4u : 0u);
+            key = (oct << 24) | (m21 << 3) | sub;
         }
         L.sort_keys[0][j] = key;
         L.sort_vals[0][j] = pos;
@@ -852,29 +858,34 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
     const WfHostSync *hs = L.sort_mode != 0u || (packet && packet_census_out) ? host_sync : nullptr;
     if (hs && (!hs->counts || !hs->events || hs->n_events < (int)L.ray_depth + 1))
         hs = nullptr;
+    // the per-bounce size read-back (one host wait per bounce from bounce 2 on) is only worth its latency where a sort follows; an unsorted
+    // pass (a small one, rt_scene.cpp; or RT_SORT_OFF) is queued in one go and only the packet census, if any, is waited for once
+    const bool want_bound = hs && L.sort_mode != 0u;
     uint32_t bound = L.n_paths; // upper bound of the queue entering the bounce about to be launched
     bool census_pending = false; // the packet census of bounce 0 is on its way to the pinned words (event 0)
     for (uint32_t b = 0; b < L.ray_depth; ++b) {
         L.order = nullptr; // primary rays: dense and coherent as generated
         if (b > 0) {
-            if (hs && b >= 2) { // size of queue b - 1, an upper bound of queue b
+            if (census_pending && b == 2) { // bounce 0's census: its copy is two bounces behind the queue head by now
+                if ((e = hipEventSynchronize(hs->events[0])) != hipSuccess)
+                    return e;
+                std::memcpy(packet_census_out, hs->counts + WF_HOST_CENSUS_WORD, 2 * sizeof(unsigned long long));
+                census_pending = false;
+            }
+            if (want_bound && b >= 2) { // size of queue b - 1, an upper bound of queue b
                 if ((e = hipEventSynchronize(hs->events[b - 1])) != hipSuccess)
                     return e;
                 bound = hs->counts[b - 1];
-                if (census_pending) { // copied before event 1 was recorded: it has landed
-                    std::memcpy(packet_census_out, hs->counts + WF_HOST_CENSUS_WORD, 2 * sizeof(unsigned long long));
-                    census_pending = false;
-                }
                 if (bound == 0)
                     break;
             }
-            const bool sort = hs && L.sort_mode != 0u && bound >= 4096u;
+            const bool sort = want_bound && bound >= 4096u;
             // dense ray index -> slot of paths_in (wf_shade's sub-queue regions), with the coherence keys when a sort follows
             const uint32_t kb = (bound + 255u) / 256u < (uint32_t)num_cus * 16u ? (bound + 255u) / 256u : (uint32_t)num_cus * 16u;
             WF_LAUNCH(wf_sort_keys, dim3(kb > 0 ? kb : 1), block, 0, stream, S, L, sort ? 0 : 1, bound);
             if (sort) {
                 size_t tmp = L.sort_temp_bytes;
-                hipError_t se = rocprim::radix_sort_pairs(L.sort_temp, tmp, L.sort_keys[0], L.sort_keys[1], L.sort_vals[0], L.sort_vals[1], (size_t)bound, 0u, L.sort_mode >= 4 ? 24u : 21u, stream);
+                hipError_t se = rocprim::radix_sort_pairs(L.sort_temp, tmp, L.sort_keys[0], L.sort_keys[1], L.sort_vals[0], L.sort_vals[1], (size_t)bound, 0u, L.sort_mode == 6 ? 27u : L.sort_mode >= 4 ? 24u : 21u, stream);
                 if (se != hipSuccess)
                     return se;
             }
@@ -916,7 +927,7 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
                 return e;
             census_pending = true;
         }
-        if (hs && b + 1 < L.ray_depth) { // size of queue b + 1 -> pinned word b + 1 (read by bounce b + 2)
+        if (want_bound && b + 1 < L.ray_depth) { // size of queue b + 1 -> pinned word b + 1 (read by bounce b + 2)
             if ((e = hipMemcpyAsync(hs->counts + b + 1, L.counters + WF_CNT_IN, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
                 return e;
             if ((e = hipEventRecord(hs->events[b + 1], stream)) != hipSuccess)
@@ -940,7 +951,7 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
 size_t wavefront_sort_temp_bytes(size_t n) {
     size_t tmp = 0;
     uint32_t *k = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp, k, k, k, k, n, 0u, 24u, (hipStream_t) nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, k, k, k, k, n, 0u, 27u, (hipStream_t) nullptr);
     return tmp;
 }
 

@@ -254,6 +254,19 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) 
     bool exhausted = n_in == 0; // wave-uniform
     uint32_t q_lo = 0, q_hi = 0;
     TicketState tks = ticket_init();
+#ifdef RT_DIAG_CYCLES
+    // section census of the persistent loop (development build only): wave cycles between s_memtime stamps, trips and lanes per section
+    unsigned long long dg_refill = 0, dg_node = 0, dg_tri = 0, dg_pop = 0, dg_nodes_n = 0, dg_nodes_lanes = 0, dg_tri_n = 0, dg_tri_lanes = 0, dg_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long dg_start = dg_t;
+#define WDG_STAMP(acc)                                                \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        acc += now_ - dg_t;                                           \
+        dg_t = now_;                                                  \
+    } while (0)
+#else
+#define WDG_STAMP(acc) do { } while (0)
+#endif
     for (;;) {
         const bool idle = T.done;
         const unsigned long long im = __ballot(idle);
@@ -274,6 +287,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) 
             }
             q_lo += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
         }
+        WDG_STAMP(dg_refill);
         // unwind, once per trip, straight-line: a lane whose group has no pending slot and that has no pending triangle takes
         // the newest stacked group, or has finished
         {
@@ -295,6 +309,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) 
                 T.done = true;
             }
         }
+        WDG_STAMP(dg_pop);
         const bool waiting = !T.done && T.tm != 0u;
         const bool stepper = !T.done && T.tm == 0u && (T.gy >> 24) != 0u;
         const unsigned long long wm = __ballot(waiting), sm = __ballot(stepper);
@@ -305,11 +320,29 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) 
                 break;
             continue;
         }
-        if (sm == 0ull || __popcll(wm) >= RT_WIDE_TRI_MIN)
+        if (sm == 0ull || __popcll(wm) >= RT_WIDE_TRI_MIN) {
             wide_tri_batch<STATS>(T, S.scene, waiting, s_owner, s_min, s_bc, st);
-        else if (stepper)
-            wide_node_step<STATS>(T, nodes, stk, st);
+#ifdef RT_DIAG_CYCLES
+            dg_tri_n += 1, dg_tri_lanes += (unsigned long long)__popcll(wm);
+#endif
+            WDG_STAMP(dg_tri);
+        } else {
+            if (stepper)
+                wide_node_step<STATS>(T, nodes, stk, st);
+#ifdef RT_DIAG_CYCLES
+            dg_nodes_n += 1, dg_nodes_lanes += (unsigned long long)__popcll(sm);
+#endif
+            WDG_STAMP(dg_node);
+        }
     }
+#ifdef RT_DIAG_CYCLES
+    if ((threadIdx.x & 63u) == 0u && L.diag) {
+        unsigned long long *dg = reinterpret_cast<unsigned long long *>(L.diag);
+        atomicAdd(dg + 0, dg_refill), atomicAdd(dg + 1, dg_pop), atomicAdd(dg + 2, dg_node), atomicAdd(dg + 3, dg_tri);
+        atomicAdd(dg + 4, __builtin_amdgcn_s_memtime() - dg_start), atomicAdd(dg + 5, 1ull);
+        atomicAdd(dg + 6, dg_nodes_n), atomicAdd(dg + 7, dg_nodes_lanes), atomicAdd(dg + 8, dg_tri_n), atomicAdd(dg + 9, dg_tri_lanes);
+    }
+#endif
     st.flush(L.stats);
 }
 

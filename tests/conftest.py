@@ -114,3 +114,30 @@ def scene000_box_gltf(rt, sg, out_dir, yfov=1.2):
     b = dict(a, primitives=[], bg_color=np.ones(3, dtype=np.float32))
     sc = sg.scene_from_arrays(b, yfov=yfov, rotation=(0.0, 0.0, 0.0, 1.0), face_normals=True)
     return sg.write_gltf(sc, os.path.join(str(out_dir), "scene000_box.gltf")), a
+
+
+def explain_differing_pixels(gpu, orc, parity_dev, prod_dev, W, H, spp, seed, pixels):
+    """Why a production image differs from the parity image in `pixels` (row, col): the oracle replays each pixel's paths (device-RNG mode) and
+    logs every ray they cast; the rays go through both scenes' own closest-hit kernels. Up to the first differing hit the production path IS the
+    parity path, so that hit names the cause. Allowed by the production contract: an exact tie (t bit-equal, another triangle) or a
+    hit the reference's near-local pruning skips (bvh.h:216-223), which the production traversal finds CLOSER by rounding (<= 1e-6 relative).
+    Returns one record per pixel; raises on anything else."""
+    out = []
+    for (y, x) in pixels:
+        rays, smp = orc.trace_pixel(W, H, spp, int(y) * W + int(x), seed=seed)
+        pp, pb, _ = parity_dev.cast_rays_ex(rays, gpu.RT_CAST_EXTEND)
+        qp, qb, _ = prod_dev.cast_rays_ex(rays, gpu.RT_CAST_EXTEND)
+        op, ob = orc.cast_rays(rays)
+        assert np.array_equal(pp, op) and np.array_equal(pb.view(np.uint32), ob.view(np.uint32))  # the parity scene is the oracle's, also on these rays
+        diff = np.nonzero((pp != qp) | (pb[:, 2].view(np.uint32) != qb[:, 2].view(np.uint32)))[0]
+        assert len(diff) > 0, f"pixel ({y}, {x}): images differ but every ray of its parity paths has the same closest hit in both scenes"
+        k = int(diff[0])
+        tp, tq = float(pb[k, 2]), float(qb[k, 2])
+        if tp == tq and pp[k] != qp[k]:
+            cause = "exact tie: same t, another triangle"
+        elif qp[k] != 0xFFFFFFFF and (pp[k] == 0xFFFFFFFF or tq < tp) and (pp[k] == 0xFFFFFFFF or (tp - tq) <= 1e-6 * tp):
+            cause = "closer hit the reference's near-local pruning skips (bvh.h:216-223)"
+        else:
+            raise AssertionError(f"pixel ({y}, {x}), sample {int(smp[k])}, ray {k}: parity hit ({int(pp[k])}, t={tp!r}) vs production hit ({int(qp[k])}, t={tq!r}): outside the production contract")
+        out.append({"pixel": (int(y), int(x)), "sample": int(smp[k]), "ray_of_pixel": k, "parity": (int(pp[k]), tp), "production": (int(qp[k]), tq), "cause": cause})
+    return out

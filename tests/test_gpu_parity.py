@@ -138,7 +138,7 @@ def test_queue_shapes_match_oracle(pairs, gpu, shape):
     dev, orc, _ = pairs["room_manylights"]
     W, H, SPP = shape
     ofb, ost = orc.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=99)
-    all_keys = (gpu.RT_SORT_OCTANT_CELL_CONE, gpu.RT_SORT_CELL_OCTANT_CONE, gpu.RT_SORT_OCTANT_CELL, gpu.RT_SORT_COARSE_CELL_DIR, gpu.RT_SORT_CELL_OCTANT, gpu.RT_SORT_OFF,
+    all_keys = (gpu.RT_SORT_OCTANT_FINE_CELL_CONE, gpu.RT_SORT_OCTANT_CELL_CONE, gpu.RT_SORT_CELL_OCTANT_CONE, gpu.RT_SORT_OCTANT_CELL, gpu.RT_SORT_COARSE_CELL_DIR, gpu.RT_SORT_CELL_OCTANT, gpu.RT_SORT_OFF,
                 gpu.RT_SORT_AUTO)
     for sort in all_keys if shape == (96, 50, 2) else (gpu.RT_SORT_OCTANT_CELL_CONE, gpu.RT_SORT_OFF):
         gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=gpu.RT_RNG_DEVICE, seed=99, counters=True, sort_mode=sort)

