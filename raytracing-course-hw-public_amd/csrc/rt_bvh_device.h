@@ -11,6 +11,7 @@ struct DeviceBvh {
     DevNode *nodes = nullptr; // device memory, owned by the caller after a successful build (null when `wide` was built)
     WideNode *wide = nullptr; // the 8-wide tree, collapsed on the device (tris / attrs are then in ITS order)
     uint32_t n_wide = 0, wide_depth = 0;
+    WideGrid wide_grid{};     // the grids its nodes were snapped to (wide_grid.h)
     double wide_ms = 0;
     bool ploc = false;        // the binary tree came from PLOC (else: Karras radix tree)
     uint32_t rounds = 0;      // PLOC rounds

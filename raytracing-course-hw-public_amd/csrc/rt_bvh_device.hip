@@ -33,6 +33,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "rt_bvh_device.h"
+#include "wide_grid.h"
 #include "rt_kernels.h"
 
 namespace {
@@ -537,6 +538,7 @@ struct WideEmit {
     uint2 *queue_out;
     uint32_t n_in;
     uint32_t *counters;                 // [0] wide records allocated, [1] triangle records allocated, [2] entries of queue_out
+    WideGrid grid;                      // origins are snapped to it, cell exponents clamped to its 4-bit range (wide_grid.h), as in wide_build.cpp
 };
 __device__ __forceinline__ uint32_t dec_ksplit(unsigned long long d, int j) { return (uint32_t)(d >> (3 * (j - 2))) & 7u; }
 __device__ __forceinline__ uint32_t dec_eff(unsigned long long d, int i) { return (uint32_t)(d >> (21 + 3 * (i - 1))) & 7u; }
@@ -617,19 +619,11 @@ __global__ __launch_bounds__(64) void k_wide_emit(const WideEmit E) {
         }
     WideNode rec;
     int ebias[3];
+    float org[3]; // the node's origin: its lower corner snapped down to the scene's origin grid (what the quantised planes are measured from)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        rec.p[c] = lo[c];
-        const double ext = (double)hi[c] - (double)lo[c];
-        int e = -126;
-        if (ext > 0.0) {
-            e = (int)ceil(log2(ext / 255.0));
-            e = e < -126 ? -126 : e;
-            while (ldexp(255.0, e) < ext) // rounding of log2: the grid must span the box
-                ++e;
-            e = e > 126 ? 126 : e;
-        }
-        ebias[c] = e + 127;
+        rec.p[c] = org[c] = wide_snap_origin(E.grid, c, lo[c], nullptr);
+        ebias[c] = wide_cell_exponent(E.grid, (double)hi[c] - (double)org[c]) + 127;
         rec.e[c] = (uint8_t)ebias[c];
     }
     // ---- slots: greedy on dot(child centre - node centre, corner direction of the slot)
@@ -720,12 +714,12 @@ __global__ __launch_bounds__(64) void k_wide_emit(const WideEmit E) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double cell = ldexp(1.0, ebias[c] - 127);
-            double ql = floor(((double)kbox[i][c] - (double)lo[c]) / cell), qh = ceil(((double)kbox[i][3 + c] - (double)lo[c]) / cell);
+            double ql = floor(((double)kbox[i][c] - (double)org[c]) / cell), qh = ceil(((double)kbox[i][3 + c] - (double)org[c]) / cell);
             ql = fmin(fmax(ql, 0.0), 255.0);
             qh = fmin(fmax(qh, 0.0), 255.0);
-            while (ql > 0.0 && (double)lo[c] + ql * cell > (double)kbox[i][c])
+            while (ql > 0.0 && (double)org[c] + ql * cell > (double)kbox[i][c])
                 ql -= 1.0;
-            while (qh < 255.0 && (double)lo[c] + qh * cell < (double)kbox[i][3 + c])
+            while (qh < 255.0 && (double)org[c] + qh * cell < (double)kbox[i][3 + c])
                 qh += 1.0;
             rec.qlo[c][s] = (uint8_t)ql;
             rec.qhi[c][s] = (uint8_t)qh;
@@ -978,6 +972,12 @@ hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBv
         BUILD_TRY(hipMemcpyAsync(queue[0], &root_entry, sizeof(root_entry), hipMemcpyHostToDevice, stream));
         BUILD_TRY(hipStreamSynchronize(stream));
         WideEmit E{};
+        {
+            float s_lo[3], s_hi[3];
+            for (int c = 0; c < 3; ++c)
+                s_lo[c] = dec_f(h_bounds[c]), s_hi[c] = dec_f(h_bounds[3 + c]);
+            E.grid = out->wide_grid = make_wide_grid(s_lo, s_hi);
+        }
         E.nodes = A.nodes, E.leaf_box = A.leaf_box, E.dp_dec = A.dp_dec, E.tris_in = A.tris, E.attrs_in = A.attrs;
         E.wide = wide_nodes, E.tris_out = wide_tris, E.attrs_out = wide_attrs, E.counters = counters;
         uint32_t level_n = 1;

@@ -134,17 +134,19 @@ DEV void diag_add(int slot, unsigned long long v) {
 // Development-only section census of wf_shade (-DRT_DIAG_SHADE): wave cycles (s_memtime) and active lanes between stamps,
 // accumulated per wave in LDS and flushed to the census words at kernel end. Never compiled into the product.
 #ifdef RT_DIAG_SHADE
-enum { SD_LOAD = 0, SD_ATTR, SD_TEX, SD_SAMPLE, SD_PDF_LIGHTS, SD_BRDF, SD_FOLD, SD_STORE, SD_N };
-__shared__ unsigned long long g_sd_cyc[4][SD_N], g_sd_lanes[4][SD_N], g_sd_cnt[4][SD_N], g_sd_t[4];
-DEV void sd_stamp(int section) { // attribute the cycles since the previous stamp of this wave to `section`
+// A stamp at the END of a region (also inside a divergent branch or a loop body) attributes the wave cycles since the wave's previous stamp to
+// `section`, once plain and once weighted with the lanes active at the stamp: lane_cycles / cycles = the lanes that section really runs at.
+enum { SD_LOAD = 0, SD_ATTR, SD_TEX, SD_ALPHA, SD_S_VNDF, SD_S_COS, SD_S_LIGHT, SD_VNDF_PDF, SD_LPDF, SD_BRDF, SD_FOLD, SD_STORE, SD_N };
+__shared__ unsigned long long g_sd_cyc[4][SD_N], g_sd_lanes[4][SD_N], g_sd_t[4];
+DEV void sd_stamp(int section) {
     const unsigned long long m = __ballot(1);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     const unsigned long long now = __builtin_amdgcn_s_memtime();
     if (rank == 0) {
         const uint32_t w = threadIdx.x >> 6;
-        g_sd_cyc[w][section] += now - g_sd_t[w];
-        g_sd_lanes[w][section] += (unsigned long long)__popcll(m);
-        g_sd_cnt[w][section] += 1ull;
+        const unsigned long long dt = now - g_sd_t[w];
+        g_sd_cyc[w][section] += dt;
+        g_sd_lanes[w][section] += dt * (unsigned long long)__popcll(m);
         g_sd_t[w] = now;
     }
 }
@@ -835,6 +837,7 @@ template <bool STATS, class STK> DEV float lights_pdf(const DevScene &S, const L
             }
             if (cur == T_POP)
                 cur = sp ? stk.pop_ref(--sp) : T_DONE;
+            SD_STAMP(SD_LPDF); // (development census: one stamp per loop trip, with the lanes still walking the light BVH)
         }
     }
     return res / (float)bvh.n_tris; // res / bvh->objects.size()
@@ -1253,16 +1256,20 @@ DEV ShadeResult shade_hit(const DevScene &S, const LightTabs &LT, const Hit &h, 
         out.nrd = rd;
         return out;
     }
+    SD_STAMP(SD_ALPHA);
     const float vr = pow2(rmax(ii.roughness, MIN_ROUGHNESS)); // :563-564
     V3 dir;
     if (uniform_real(rng, 0.0f, 1.0f) <= VNDF_FACTOR) { // :565
         dir = vndf_sample(rng, vr, rd, ii.shading_normal);
+        SD_STAMP(SD_S_VNDF);
     } else if (!has_lights) { // dir_dist = cosine_dist (:449)
         dir = norm(ii.normal + sphere_uniform(rng));
+        SD_STAMP(SD_S_COS);
     } else { // mix_dist{cosine, bvh_mix} (:381-393)
         const uint32_t pick = rng.below(2);
         if (pick == 0) {
             dir = norm(ii.normal + sphere_uniform(rng));
+            SD_STAMP(SD_S_COS);
         } else { // bvh_mix_dist::sample :353-361 + triangle_dist::sample :225-239
             const uint32_t id = rng.below(S.lights.n_tris);
             const float4 *lp = LT.tris + 3u * id;
@@ -1275,6 +1282,7 @@ DEV ShadeResult shade_hit(const DevScene &S, const LightTabs &LT, const Hit &h, 
             }
             V3 p = mk(l0.x, l0.y, l0.z) + mk(l0.w, l1.x, l1.y) * v + mk(l1.z, l1.w, l2.x) * u; // a + v' * v + u' * u (DevTri: a, v, u)
             dir = norm(p - pos);
+            SD_STAMP(SD_S_LIGHT);
         }
     }
     if (isnan_f(dir.x) || isnan_f(dir.y) || isnan_f(dir.z)) { // :569-571
@@ -1282,8 +1290,8 @@ DEV ShadeResult shade_hit(const DevScene &S, const LightTabs &LT, const Hit &h, 
         out.term = ii.emission;
         return out;
     }
-    SD_STAMP(SD_SAMPLE);
     const float VNDF_p = vndf_pdf(vr, rd, ii.shading_normal, dir);
+    SD_STAMP(SD_VNDF_PDF);
     float MIS_p;
     const float cos_p = rmax(dot(ii.normal, dir) / PI_F, 0.0f); // cosine_dist::pdf :123-128
     if (!has_lights) {
@@ -1293,7 +1301,6 @@ DEV ShadeResult shade_hit(const DevScene &S, const LightTabs &LT, const Hit &h, 
         r += cos_p;
         r += lights_pdf<STATS>(S, LT, pos, dir, stk, st);
         MIS_p = r / 2.0f;
-        SD_STAMP(SD_PDF_LIGHTS);
     }
     const float p = VNDF_FACTOR * VNDF_p + (1 - VNDF_FACTOR) * MIS_p;
     if (p < EPS) { // :576-578

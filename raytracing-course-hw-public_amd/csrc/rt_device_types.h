@@ -55,6 +55,10 @@ struct alignas(16) DevAttr {
 };
 static_assert(sizeof(DevAttr) == 128, "DevAttr must be 128 bytes");
 
+struct alignas(16) uint4_pod { // a 16-byte unit of the wide blob (no HIP vector types in this header: host code includes it too)
+    uint32_t x, y, z, w;
+};
+
 struct alignas(16) DevLightAux { // per light triangle (light-BVH order): triangle::normal(), triangle::square()
     float normal[3];
     float area;
@@ -119,6 +123,28 @@ static_assert(sizeof(WideNode) == 80, "WideNode must be 80 bytes");
 #endif
 #define RT_WIDE_MAX_LEAF_TRIS 3u
 
+// ---- what the wide kernels READ: the same tree, re-encoded (round 4). An 80-byte record at an 80-byte stride crosses a 128-byte line for
+// half of all nodes and costs a lane 5 vector-L1 tag accesses (one per 16-byte piece), and that access rate is what bounds wf_extend_wide
+// (profiles/r04_variants.txt). The packed node is 64 bytes, 64-byte aligned: 4 accesses, never more than one line, two nodes per line.
+//   piece 0  w0  base: 16-byte unit index (into the blob below) of this node's first inner child; its leaf triangles follow its inner children
+//            w1  bits 0..23 slot states, 3 bits per slot: 000 empty, 100 inner node, 001 / 011 / 111 a leaf slot of 1 / 2 / 3 triangles (for the
+//                leaf slots this IS WideNode::tri_mask); bits 24..27 / 28..31: cell exponents of x / y, relative to WideGrid::e_base
+//            w2  bits 0..19 origin x, bits 20..31 the low 12 bits of origin y        (origins are multiples of WideGrid::g above WideGrid::base:
+//            w3  bits 0..7 the high 8 bits of origin y, 8..27 origin z, 28..31 exponent z    the builders snap every node origin to that grid)
+//   pieces 1..3  the 48 plane bytes exactly as WideNode::qlo / qhi.
+// Nodes and triangle records live in ONE array of 16-byte units (the "blob"): [root][children of node A][triangles of A][pad to 64 B][children of B]...
+// A node is 4 units, a triangle record (DevTri: 48 B) 3 units; DevTri::pad of a record in the blob holds its index into DevTri[] / DevAttr[]
+// (the hit records and wf_shade keep using that index). One 32-bit base per node addresses 64 GB.
+struct WideGrid {
+    float base[3]; // per axis: a multiple of g at or below the scene's lower corner
+    float g;       // origin granularity, a power of two: every node origin is base + m * g with m < 2^20, exactly representable
+    int32_t e_base; // cell exponents are stored as e - e_base in 4 bits (e = unbiased exponent of the cell size); smaller cells are clamped up
+    uint32_t pad_;
+};
+#define RT_WIDE_ORIGIN_BITS 20u
+#define RT_WIDE_NODE_UNITS 4u
+#define RT_WIDE_TRI_UNITS 3u
+
 struct DevBvh {
     const DevNode *nodes;
     const DevTri *tris;
@@ -126,10 +152,11 @@ struct DevBvh {
     uint32_t n_tris; // BVH::objects.size()
     uint32_t fast_ok; // every node box coordinate is 0 or has magnitude in [2^-37, 2^40] (div_exact_fast precondition)
     uint32_t lds_inner; // light BVH only: 0, or 1 + number of inner nodes when nodes + triangles + aux fit RT_SHADE_LIGHTS_F4 (wf_shade stages them in LDS)
-    const WideNode *wide; // scene BVH only: non-null = the scene was built wide (RT_BUILD_WIDE); root is wide[0], `nodes` is null,
-                          // `tris` (and DevScene::attrs) are in the wide tree's triangle order
-    uint32_t n_wide;
-    uint32_t pad_;
+    const uint4_pod *wide; // scene BVH only: non-null = the scene was built wide (RT_BUILD_WIDE): the packed blob (above), root = unit 0;
+                           // `nodes` is null, `tris` (and DevScene::attrs) are in the wide tree's triangle order
+    uint32_t n_wide;       // wide nodes
+    uint32_t n_units;      // 16-byte units of the blob
+    WideGrid grid;
 };
 #define RT_SHADE_LIGHTS_F4 384 /* 6 KB of LDS in wf_shade: 4 pieces per inner node + 4 per light triangle (e.g. 31 nodes + 64 lights) */
 

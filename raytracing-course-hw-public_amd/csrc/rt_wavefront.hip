@@ -490,7 +490,7 @@ template <bool STATS, bool LIGHTS_LDS, bool ENV> __global__ __launch_bounds__(25
     s_gam[threadIdx.x] = S.lut_gamma[threadIdx.x];
 #ifdef RT_DIAG_SHADE
     if (threadIdx.x < 4u * SD_N)
-        (&g_sd_cyc[0][0])[threadIdx.x] = 0ull, (&g_sd_lanes[0][0])[threadIdx.x] = 0ull, (&g_sd_cnt[0][0])[threadIdx.x] = 0ull;
+        (&g_sd_cyc[0][0])[threadIdx.x] = 0ull, (&g_sd_lanes[0][0])[threadIdx.x] = 0ull;
     if ((threadIdx.x & 63u) == 0u)
         g_sd_t[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
 #endif
@@ -576,11 +576,10 @@ template <bool STATS, bool LIGHTS_LDS, bool ENV> __global__ __launch_bounds__(25
     }
 #ifdef RT_DIAG_SHADE
     __syncthreads();
-    if (threadIdx.x < 4u * SD_N && L.diag) { // census words 0..7: cycles per section, 8..15: active lanes, 16..23: stamps (summed over waves)
+    if (threadIdx.x < 4u * SD_N && L.diag) { // census words 0..11: wave cycles per section, 12..23: lane-weighted cycles (summed over waves)
         unsigned long long *dg = reinterpret_cast<unsigned long long *>(L.diag);
         atomicAdd(dg + (threadIdx.x % SD_N), (&g_sd_cyc[0][0])[threadIdx.x]);
-        atomicAdd(dg + 8 + (threadIdx.x % SD_N), (&g_sd_lanes[0][0])[threadIdx.x]);
-        atomicAdd(dg + 16 + (threadIdx.x % SD_N), (&g_sd_cnt[0][0])[threadIdx.x]);
+        atomicAdd(dg + SD_N + (threadIdx.x % SD_N), (&g_sd_lanes[0][0])[threadIdx.x]);
     }
 #endif
     st.flush(L.stats);

@@ -3,8 +3,11 @@
 // persistent wavefronts, lanes refilled from the ray queue as their traversals end, hits stored at the ray's queue position.
 //
 // What replaces the reference's recursion (BVH::intersect_ray, src/bvh.h:195-235):
-//   * a node visit tests EIGHT child boxes from one 80-byte record (5 vector-L1 accesses per lane; the binary node costs 4 for
-//     two boxes and the L1 access rate is what bounds wf_extend, profiles/r02_l1_roof.txt);
+//   * a node visit tests EIGHT child boxes from one 64-byte record, 64-byte aligned (4 vector-L1 accesses per lane, never more than one
+//     128-byte line; the binary node costs 4 for two boxes and the L1 access rate is what bounds these kernels, profiles/r02_l1_roof.txt,
+//     profiles/r04_variants.txt). The builders emit 80-byte WideNode records; rt_wide_pack.hip re-encodes them (origin as 3 x 20 bits on a
+//     scene grid, 4-bit exponents, slot states) and lays nodes and triangle records out in ONE array of 16-byte units: a node's inner
+//     children, then its leaf triangles, addressed by one base;
 //   * every box is culled against the GLOBAL best hit so far (the reference prunes only between siblings, bvh.h:216-223);
 //   * no distance sort: a node's slots are laid out by octant (wide_build.cpp), so the hit slots are visited front to back by
 //     taking them in the order of decreasing (slot ^ oct ^ 7), oct = the ray's direction signs; the pending rest of a node is
@@ -73,20 +76,46 @@ DEV float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u); } // v_
 // The eight slab tests of one node record against one ray: bit i of the result = the ray meets slot i's box within [EPS, tlim].
 // t = q * ad + b stands for ((p + q * cell) - o) / d. Error margin: the two products and the sum are each rounded once
 // (<= 3 half-ulps of the larger magnitude), 1/d itself is off by half an ulp: 2^-21 of (|b| + 255 |ad|) covers it 4x over.
-DEV uint32_t wide_test8(const uint4 n0, const uint4 n2, const uint4 n3, const uint4 n4, V3 o, V3 idir, float tlim) {
-    const uint32_t ew = n0.w;
-    const float adx = __uint_as_float((ew & 255u) << 23) * idir.x, ady = __uint_as_float(((ew >> 8) & 255u) << 23) * idir.y,
-                adz = __uint_as_float(((ew >> 16) & 255u) << 23) * idir.z;
-    const float bx = (__uint_as_float(n0.x) - o.x) * idir.x, by = (__uint_as_float(n0.y) - o.y) * idir.y, bz = (__uint_as_float(n0.z) - o.z) * idir.z;
+// The packed node's header (piece 0, rt_device_types.h): origin = grid base + m * g (exact: wide_grid.h), cell = 2^(e4 + e_base).
+struct WideHdr {
+    V3 p;      // the node's origin
+    V3 cell;   // cell sizes
+    uint32_t base, imask, tri_mask; // first inner child (16-byte unit index), inner-slot mask, leaf triangles (3 bits per slot, as WideNode::tri_mask)
+};
+DEV WideHdr wide_decode(const uint4 h, const WideGrid &G) {
+    WideHdr H;
+    const uint32_t mx = h.z & 0xFFFFFu, my = __builtin_amdgcn_alignbit(h.w, h.z, 20) & 0xFFFFFu, mz = (h.w >> 8) & 0xFFFFFu;
+    H.p = mk(__builtin_fmaf((float)mx, G.g, G.base[0]), __builtin_fmaf((float)my, G.g, G.base[1]), __builtin_fmaf((float)mz, G.g, G.base[2]));
+    const uint32_t eb = (uint32_t)(G.e_base + 127);
+    H.cell = mk(__uint_as_float((((h.y >> 24) & 15u) + eb) << 23), __uint_as_float(((h.y >> 28) + eb) << 23), __uint_as_float(((h.w >> 28) + eb) << 23));
+    const uint32_t state = h.y & 0xFFFFFFu;
+    uint32_t t = (state >> 2) & ~state & 0x249249u; // bit 3s: slot s holds the pattern 100 = an inner node
+    H.tri_mask = state & ~(t << 2);
+    t = (t | (t >> 2)) & 0x0C30C3u; // every third bit -> consecutive bits
+    t = (t | (t >> 4)) & 0x00F00Fu;
+    H.imask = (t | (t >> 8)) & 0xFFu;
+    H.base = h.x;
+    return H;
+}
+
+DEV uint32_t wide_test8(const WideHdr &H, const uint4 n2, const uint4 n3, const uint4 n4, V3 o, V3 idir, float tlim) {
+    const float adx = H.cell.x * idir.x, ady = H.cell.y * idir.y, adz = H.cell.z * idir.z;
+    const float bx = (H.p.x - o.x) * idir.x, by = (H.p.y - o.y) * idir.y, bz = (H.p.z - o.z) * idir.z;
     const float ex = __builtin_fmaf(255.0f, __builtin_fabsf(adx), __builtin_fabsf(bx)) * 4.76837158203125e-07f,
                 ey = __builtin_fmaf(255.0f, __builtin_fabsf(ady), __builtin_fabsf(by)) * 4.76837158203125e-07f,
                 ez = __builtin_fmaf(255.0f, __builtin_fabsf(adz), __builtin_fabsf(bz)) * 4.76837158203125e-07f;
     const float bx0 = bx - ex, bx1 = bx + ex, by0 = by - ey, by1 = by + ey, bz0 = bz - ez, bz1 = bz + ez;
-    // near / far planes per axis by the direction sign: words {slots 0..3, slots 4..7}
-    const bool nx = idir.x < 0.0f, ny = idir.y < 0.0f, nz = idir.z < 0.0f;
-    const uint32_t xn0 = nx ? n3.z : n2.x, xn1 = nx ? n3.w : n2.y, xf0 = nx ? n2.x : n3.z, xf1 = nx ? n2.y : n3.w;
-    const uint32_t yn0 = ny ? n4.x : n2.z, yn1 = ny ? n4.y : n2.w, yf0 = ny ? n2.z : n4.x, yf1 = ny ? n2.w : n4.y;
-    const uint32_t zn0 = nz ? n4.z : n3.x, zn1 = nz ? n4.w : n3.y, zf0 = nz ? n3.x : n4.z, zf1 = nz ? n3.y : n4.w;
+    // near / far planes per axis by the direction sign: words {slots 0..3, slots 4..7}. Selected with a per-lane BIT mask (sign of 1/d smeared
+    // over the word; one v_bitop3_b32 per select), not with `cond ? a : b`: the compiler turns the latter into one v_cmp and four
+    // v_cndmask_b32_e32 reading vcc, and on gfx950 every vcc-reading VOP2 select that does not directly follow its compare holds the SIMD for
+    // ~16-23 cycles against ~3.3 for a bitwise op (tools/ubench/valu_rates.hip, profiles/r04_variants.txt item 2): 12 selects per node visit.
+    uint32_t mx = (uint32_t)((int32_t)__float_as_uint(idir.x) >> 31), my = (uint32_t)((int32_t)__float_as_uint(idir.y) >> 31),
+             mz = (uint32_t)((int32_t)__float_as_uint(idir.z) >> 31);
+    asm volatile("" : "+v"(mx), "+v"(my), "+v"(mz)); // opaque: otherwise the masks are recognised as sign tests and the selects come back as v_cndmask on vcc
+    auto pick = [](uint32_t m, uint32_t if_set, uint32_t if_clear) { return (if_set & m) | (if_clear & ~m); };
+    const uint32_t xn0 = pick(mx, n3.z, n2.x), xn1 = pick(mx, n3.w, n2.y), xf0 = pick(mx, n2.x, n3.z), xf1 = pick(mx, n2.y, n3.w);
+    const uint32_t yn0 = pick(my, n4.x, n2.z), yn1 = pick(my, n4.y, n2.w), yf0 = pick(my, n2.z, n4.x), yf1 = pick(my, n2.w, n4.y);
+    const uint32_t zn0 = pick(mz, n4.z, n3.x), zn1 = pick(mz, n4.w, n3.y), zf0 = pick(mz, n3.x, n4.z), zf1 = pick(mz, n3.y, n4.w);
     uint32_t h = 0u;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -120,12 +149,12 @@ DEV uint32_t wide_leaf_tris(uint32_t l, uint32_t tri_mask) {
 
 // One node visit: take the next child of the current group (pushing the rest back if any), fetch its record and test its
 // eight boxes against [EPS, best.t]. Leaves the child's own group in (gx, gy) and its hit triangles in (tbase, tm, tall).
-template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const WideNode *nodes, STK &stk, LaneStats<STATS> &st) {
+template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const uint4 *blob, const WideGrid &G, STK &stk, LaneStats<STATS> &st) {
     const uint32_t hits = T.gy;
     const uint32_t bit = 31u - (uint32_t)__clz((int)hits);
     const uint32_t rest = hits ^ (1u << bit);
     const uint32_t slot = (bit - 24u) ^ T.oct_inv;
-    const uint32_t idx = T.gx + (uint32_t)__popc(hits & 0xFFu & ((1u << slot) - 1u));
+    const uint32_t idx = T.gx + RT_WIDE_NODE_UNITS * (uint32_t)__popc(hits & 0xFFu & ((1u << slot) - 1u)); // 16-byte unit index of the child's record
     const bool more = (rest >> 24) != 0u;
     if (more & (T.sp > 0))
         stk.push(T.sp - 1, T.top_x, __uint_as_float(T.top_y)); // spill the previous top
@@ -133,17 +162,18 @@ template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const WideNod
     T.top_y = more ? rest : T.top_y;
     T.sp += more ? 1 : 0;
 
-    const uint4 *p = reinterpret_cast<const uint4 *>(nodes + idx);
-    const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
+    const uint4 *p = blob + idx;
+    const uint4 n0 = p[0], n2 = p[1], n3 = p[2], n4 = p[3];
     st.node();
     st.box(8);
-    const uint32_t imask = n0.w >> 24;
-    const uint32_t h = wide_test8(n0, n2, n3, n4, T.o, T.idir, T.best.t);
-    T.gx = n1.x;
+    const WideHdr H = wide_decode(n0, G);
+    const uint32_t imask = H.imask;
+    const uint32_t h = wide_test8(H, n2, n3, n4, T.o, T.idir, T.best.t);
+    T.gx = H.base;
     T.gy = (wide_priority(h & imask, T.oct_inv) << 24) | imask;
-    T.tbase = n1.y;
-    T.tall = n1.z;
-    T.tm = wide_leaf_tris(h & ~imask, n1.z);
+    T.tbase = H.base + RT_WIDE_NODE_UNITS * (uint32_t)__popc(imask); // the node's triangle records follow its inner children
+    T.tall = H.tri_mask;
+    T.tm = wide_leaf_tris(h & ~imask, H.tri_mask);
 #ifdef RT_WIDE_DIAG // development census through the (otherwise idle) light counters of the instrumented variant
     if (h == 0u)
         st.lhit(); // a visit that hit none of the eight boxes
@@ -157,7 +187,7 @@ template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const WideNod
 // Triangle batch, as wf_extend's leaf batch: the pending (ray, triangle) pairs of all waiting lanes are laid out densely over
 // the wave; a lane's result is the minimum of (t bits, triangle record) over its pairs: smallest t, lowest record on equal t.
 template <bool STATS>
-DEV void wide_tri_batch(WTrav &T, const DevBvh &bvh, bool waiting, uint16_t *s_owner, unsigned long long *s_min, float2 *s_bc, LaneStats<STATS> &st) {
+DEV void wide_tri_batch(WTrav &T, const uint4 *blob, bool waiting, uint16_t *s_owner, unsigned long long *s_min, float4 *s_bc, LaneStats<STATS> &st) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t have = waiting ? (uint32_t)__popc(T.tm) : 0u;
     const uint32_t n = have < RT_WIDE_COOP_MAX ? have : RT_WIDE_COOP_MAX;
@@ -196,11 +226,11 @@ DEV void wide_tri_batch(WTrav &T, const DevBvh &bvh, bool waiting, uint16_t *s_o
         const bool valid = q < total;
         const uint32_t ow = valid ? (uint32_t)s_owner[q] : 0u;
         const int src = (int)(ow & 63u);
-        const uint32_t kk = (uint32_t)__shfl((int)T.tbase, src) + (ow >> 8);
+        const uint32_t kk = (uint32_t)__shfl((int)T.tbase, src) + RT_WIDE_TRI_UNITS * (ow >> 8); // 16-byte unit index of the triangle record
         const V3 o = mk(__shfl(T.o.x, src), __shfl(T.o.y, src), __shfl(T.o.z, src));
         const V3 d = mk(__shfl(T.d.x, src), __shfl(T.d.y, src), __shfl(T.d.z, src));
         if (valid) {
-            const float4 *p = reinterpret_cast<const float4 *>(bvh.tris + kk);
+            const float4 *p = reinterpret_cast<const float4 *>(blob + kk);
             const float4 r0 = p[0], r1 = p[1], r2 = p[2];
             st.tri();
             V3 xs;
@@ -208,8 +238,8 @@ DEV void wide_tri_batch(WTrav &T, const DevBvh &bvh, bool waiting, uint16_t *s_o
                 const unsigned long long key = ((unsigned long long)__float_as_uint(xs.z) << 32) | (unsigned long long)kk;
                 atomicMin(&s_min[src], key);
                 __threadfence_block();
-                if (s_min[src] == key) // this pair leads its ray so far: publish its barycentrics
-                    s_bc[src] = make_float2(xs.x, xs.y);
+                if (s_min[src] == key) // this pair leads its ray so far: publish its barycentrics and the record's DevTri / DevAttr index (DevTri::pad)
+                    s_bc[src] = make_float4(xs.x, xs.y, r2.w, 0.0f);
             }
         }
     }
@@ -218,9 +248,9 @@ DEV void wide_tri_batch(WTrav &T, const DevBvh &bvh, bool waiting, uint16_t *s_o
         const unsigned long long key = s_min[lane];
         if (key != ~0ull) {
             const float t = __uint_as_float((uint32_t)(key >> 32));
-            const float2 bc = s_bc[lane];
+            const float4 bc = s_bc[lane];
             if (T.best.t > t) { // strict: the first-found triangle keeps an exact tie (update_intersection, bvh.h:132)
-                T.best.k = (uint32_t)key;
+                T.best.k = __float_as_uint(bc.z);
                 T.best.b = bc.x;
                 T.best.c = bc.y;
                 T.best.t = t;
@@ -233,15 +263,16 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) 
     __shared__ uint32_t s_stack[STACK_LDS_DWORDS_W(RT_WIDE_LDS_DEPTH, 2)];
     __shared__ uint16_t s_owner_all[4][64 * RT_WIDE_COOP_MAX + RT_WIDE_COOP_MAX]; // + overshoot of the unpredicated owner stores
     __shared__ unsigned long long s_min_all[4][64];
-    __shared__ float2 s_bc_all[4][64];
+    __shared__ float4 s_bc_all[4][64];
     const uint32_t wave = threadIdx.x >> 6;
     uint16_t *s_owner = s_owner_all[wave];
     unsigned long long *s_min = s_min_all[wave];
-    float2 *s_bc = s_bc_all[wave];
+    float4 *s_bc = s_bc_all[wave];
     LaneStats<STATS> st;
     RT_DECLARE_RING_STACK_W(stk, RT_WIDE_LDS_DEPTH, 2, s_stack, L.stack_overflow, L.stack_stride);
     const uint32_t n_in = L.counters[WF_CNT_IN];
-    const WideNode *nodes = S.scene.wide;
+    const uint4 *blob = reinterpret_cast<const uint4 *>(S.scene.wide);
+    const WideGrid G = S.scene.grid;
     WTrav T;
     T.o = T.d = T.idir = mk(0.f, 0.f, 0.f);
     T.oct_inv = 0u;
@@ -321,14 +352,14 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) 
             continue;
         }
         if (sm == 0ull || __popcll(wm) >= RT_WIDE_TRI_MIN) {
-            wide_tri_batch<STATS>(T, S.scene, waiting, s_owner, s_min, s_bc, st);
+            wide_tri_batch<STATS>(T, blob, waiting, s_owner, s_min, s_bc, st);
 #ifdef RT_DIAG_CYCLES
             dg_tri_n += 1, dg_tri_lanes += (unsigned long long)__popcll(wm);
 #endif
             WDG_STAMP(dg_tri);
         } else {
             if (stepper)
-                wide_node_step<STATS>(T, nodes, stk, st);
+                wide_node_step<STATS>(T, blob, G, stk, st);
 #ifdef RT_DIAG_CYCLES
             dg_nodes_n += 1, dg_nodes_lanes += (unsigned long long)__popcll(sm);
 #endif
@@ -364,7 +395,8 @@ template <bool STATS> __global__ __launch_bounds__(256, 8) void wf_extend_wide_p
     LaneStats<STATS> st;
     const uint32_t n_in = L.counters[WF_CNT_IN];
     const uint32_t lane = threadIdx.x & 63u;
-    const WideNode *nodes = S.scene.wide;
+    const uint4 *blob = reinterpret_cast<const uint4 *>(S.scene.wide);
+    const WideGrid G = S.scene.grid;
     unsigned long long n_trips = 0ull, n_lanes = 0ull; // wave-uniform
     for (;;) {
         uint32_t base = 0;
@@ -404,48 +436,49 @@ template <bool STATS> __global__ __launch_bounds__(256, 8) void wf_extend_wide_p
                 const uint32_t bit = 31u - (uint32_t)__clz((int)gy);
                 const uint32_t rest = gy ^ (1u << bit);
                 const uint32_t slot = (bit - 24u) ^ oct_inv;
-                uint32_t idx = gx + (uint32_t)__popc(gy & 0xFFu & ((1u << slot) - 1u));
+                uint32_t idx = gx + RT_WIDE_NODE_UNITS * (uint32_t)__popc(gy & 0xFFu & ((1u << slot) - 1u));
                 if ((rest >> 24) != 0u && sp < RT_MAX_STACK) {
                     if (lane == 0u)
                         s_stack[sp] = make_uint2(gx, rest);
                     ++sp;
                 }
-                idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx); // the record's address is scalar: one s_load per piece for the whole wave
+                idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx); // the record's address is scalar: ONE 64-byte s_load for the whole wave
                 typedef uint32_t U4v __attribute__((ext_vector_type(4)));
                 typedef const __attribute__((address_space(4))) U4v *ConstU4;
-                ConstU4 p = (ConstU4)(unsigned long long)(nodes + idx);
-                const U4v v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3], v4 = p[4];
-                const uint4 n0 = make_uint4(v0.x, v0.y, v0.z, v0.w), n1 = make_uint4(v1.x, v1.y, v1.z, v1.w), n2 = make_uint4(v2.x, v2.y, v2.z, v2.w),
-                            n3 = make_uint4(v3.x, v3.y, v3.z, v3.w), n4 = make_uint4(v4.x, v4.y, v4.z, v4.w);
-                const uint32_t imask = n0.w >> 24;
-                const uint32_t h = wide_test8(n0, n2, n3, n4, o, idir, best.t);
+                ConstU4 p = (ConstU4)(unsigned long long)(blob + idx);
+                const U4v v0 = p[0], v2 = p[1], v3 = p[2], v4 = p[3];
+                const uint4 n0 = make_uint4(v0.x, v0.y, v0.z, v0.w), n2 = make_uint4(v2.x, v2.y, v2.z, v2.w), n3 = make_uint4(v3.x, v3.y, v3.z, v3.w),
+                            n4 = make_uint4(v4.x, v4.y, v4.z, v4.w);
+                const WideHdr H = wide_decode(n0, G); // wave-uniform: scalar arithmetic
+                const uint32_t imask = H.imask;
+                const uint32_t h = wide_test8(H, n2, n3, n4, o, idir, best.t);
                 if (have) {
                     st.node();
                     st.box(8);
                 }
-                uint32_t H = 0u; // slots ANY lane hit
+                uint32_t Hany = 0u; // slots ANY lane hit
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    H |= __ballot((h >> i) & 1u) != 0ull ? (1u << i) : 0u;
+                    Hany |= __ballot((h >> i) & 1u) != 0ull ? (1u << i) : 0u;
                 ++n_trips;
                 n_lanes += (uint32_t)__popcll(__ballot(h != 0u));
-                gx = n1.x;
-                gy = (wide_priority(H & imask, oct_inv) << 24) | imask;
+                gx = H.base;
+                gy = (wide_priority(Hany & imask, oct_inv) << 24) | imask;
                 // triangles of the leaf slots some lane met, in record order; a lane tests those of the slots IT met
-                uint32_t tm = wide_leaf_tris(H & ~imask, n1.z);
-                const uint32_t tall = n1.z, tbase = n1.y;
+                uint32_t tm = wide_leaf_tris(Hany & ~imask, H.tri_mask);
+                const uint32_t tall = H.tri_mask, tbase = H.base + RT_WIDE_NODE_UNITS * (uint32_t)__popc(imask);
                 while (tm != 0u) {
                     const uint32_t b = (uint32_t)__ffs((int)tm) - 1u;
                     tm &= tm - 1u;
-                    uint32_t k = tbase + (uint32_t)__popc(tall & ((1u << b) - 1u));
+                    uint32_t k = tbase + RT_WIDE_TRI_UNITS * (uint32_t)__popc(tall & ((1u << b) - 1u));
                     k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-                    ConstF4 tp = as_const_f4(S.scene.tris + k);
+                    ConstF4 tp = as_const_f4(blob + k);
                     const F4v r0 = tp[0], r1 = tp[1], r2 = tp[2];
                     if ((h >> (b / 3u)) & 1u) {
                         st.tri();
                         V3 xs;
                         if (tri_hit(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), o, d, EPS, xs) && best.t > xs.z) {
-                            best.k = k;
+                            best.k = __float_as_uint(r2.w); // DevTri::pad of a blob record: its DevTri / DevAttr index
                             best.b = xs.x;
                             best.c = xs.y;
                             best.t = xs.z;

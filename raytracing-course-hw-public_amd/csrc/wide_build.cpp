@@ -16,6 +16,7 @@
 //      kernel visit them front to back from the ray's direction signs alone; inner children and leaf triangles are laid out
 //      consecutively per node; boxes are quantised with floor / ceil on the node's power-of-two grid and verified.
 #include "wide_build.h"
+#include "wide_grid.h"
 
 #include <algorithm>
 #include <cmath>
@@ -235,6 +236,7 @@ WideBvh build_wide(const BinBvh &bin, const float *positions, float cost_node, f
     const std::vector<WNode> &N = W.n; // children precede parents in index order: a plain loop is a bottom-up pass
     const size_t nn = N.size();
     const double root_area = std::max(box_area(N[root].box), 1e-300);
+    out.grid = make_wide_grid(N[root].box.lo, N[root].box.hi);
 
     // ---- 2. the dynamic program
     std::vector<float> C(nn * 7);        // C[n*7 + i-1], i = 1..7
@@ -373,21 +375,17 @@ WideBvh build_wide(const BinBvh &bin, const float *positions, float cost_node, f
             child_in[bs] = bi;
         }
         // the record
+        // the record: origin snapped down to the scene's origin grid, cell exponents within the 4-bit range above e_base (wide_grid.h), so that
+        // the pack pass (rt_wide_pack.hip) can re-encode the node in 64 bytes without touching a box
         WideNode rec;
         std::memset(&rec, 0, sizeof(rec));
+        float org[3];
         for (int c = 0; c < 3; ++c)
-            rec.p[c] = nb.lo[c];
+            rec.p[c] = org[c] = wide_snap_origin(out.grid, c, nb.lo[c], nullptr);
         int ebias[3];
         double cell[3];
         for (int c = 0; c < 3; ++c) {
-            const double ext = (double)nb.hi[c] - (double)nb.lo[c];
-            int e = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
-            if (e < -126)
-                e = -126;
-            while (ext > 0 && std::ldexp(255.0, e) < ext) // rounding of log2: the grid must span the box
-                ++e;
-            if (e > 126)
-                e = 126;
+            const int e = wide_cell_exponent(out.grid, (double)nb.hi[c] - (double)org[c]);
             ebias[c] = e + 127;
             cell[c] = std::ldexp(1.0, e);
             rec.e[c] = (uint8_t)ebias[c];
@@ -406,14 +404,14 @@ WideBvh build_wide(const BinBvh &bin, const float *positions, float cost_node, f
                 continue;
             const Box3 &cb = N[kids[i].node].box;
             for (int c = 0; c < 3; ++c) {
-                double ql = std::floor(((double)cb.lo[c] - (double)nb.lo[c]) / cell[c]);
-                double qh = std::ceil(((double)cb.hi[c] - (double)nb.lo[c]) / cell[c]);
+                double ql = std::floor(((double)cb.lo[c] - (double)org[c]) / cell[c]);
+                double qh = std::ceil(((double)cb.hi[c] - (double)org[c]) / cell[c]);
                 ql = std::min(std::max(ql, 0.0), 255.0);
                 qh = std::min(std::max(qh, 0.0), 255.0);
                 // containment in exact arithmetic (doubles hold these sums exactly enough; nudge if a rounding went the wrong way)
-                while (ql > 0 && (double)nb.lo[c] + ql * cell[c] > (double)cb.lo[c])
+                while (ql > 0 && (double)org[c] + ql * cell[c] > (double)cb.lo[c])
                     ql -= 1;
-                while (qh < 255 && (double)nb.lo[c] + qh * cell[c] < (double)cb.hi[c])
+                while (qh < 255 && (double)org[c] + qh * cell[c] < (double)cb.hi[c])
                     qh += 1;
                 rec.qlo[c][s] = (uint8_t)ql;
                 rec.qhi[c][s] = (uint8_t)qh;

@@ -28,6 +28,7 @@ struct WideBvh {
     std::vector<uint32_t> order; // original triangle index of DevTri / DevAttr record k
     double sah_cost = 0;         // the collapse's cost estimate of the tree it chose (root surface area = 1)
     uint32_t depth = 0;
+    WideGrid grid{};             // the origin / exponent grids every node was snapped to (wide_grid.h): what the pack pass encodes against
 };
 // Collapse by the surface-area-heuristic dynamic program of Ylitie et al. 2017 (sec. 3): every binary subtree gets the cheapest
 // representation as a forest of at most i wide nodes / leaves (i = 1..7), leaves hold at most RT_WIDE_MAX_LEAF_TRIS triangles.

@@ -285,6 +285,40 @@ def test_device_collapse_equals_host_collapse_of_the_same_tree(gpu, sg, monkeypa
     assert t1["wide_ms"] < t2["wide_ms"]
 
 
+def test_packed_blob_decodes_to_the_builders_tree(gpu, sg):
+    """The wide kernels read the PACKED tree (rt_wide_pack.hip: 64-byte nodes, origins as 3 x 20 bits on the scene grid, 4-bit exponents, slot
+    states, nodes and triangle records in one blob). rt_bvh_wide_dump copies that blob back from HBM and decodes it; for a host-collapsed scene
+    the result must be the host builder's own 80-byte tree (rt_bvh_wide_build_host on the same triangles), record for record — origin and
+    exponents bit-equal (the builders snap to the grid, packing loses nothing), masks, all 48 plane bytes, children in slot order, every leaf
+    slot's triangles — up to the order the records are numbered in. Also on a scene far from the origin (the grid's exact-float rule)."""
+    from test_wide_build import decode
+
+    for shift in (0.0, 3000.0):
+        sc = sg.room_scene(20000, seed=9, n_lights=4, n_materials=8, tex_size=0, offset=0.1)
+        sc.positions = (sc.positions.astype(np.float64) + shift).astype(np.float32)
+        want = gpu.bvh_wide_build_host(sc.positions)
+        dev = gpu.DeviceScene(sc, wide=True)
+        got = dev.bvh_wide_dump()
+        dev.close()
+        assert len(got["nodes"]) == len(want["nodes"]) and len(got["tris"]) == len(want["order"]) == sc.n_triangles
+        A, B = decode(got["nodes"]), decode(want["nodes"])
+        prim_a, prim_b = got["tris"][:, 9], want["order"]
+        assert sorted(got["tris"][:, 11].tolist()) == list(range(sc.n_triangles))  # DevTri::pad of a blob record: its DevTri / DevAttr index, each once
+        stack, seen = [(0, 0)], 0
+        while stack:
+            a, b = stack.pop()
+            seen += 1
+            assert np.array_equal(A["p"][a].view(np.uint32), B["p"][b].view(np.uint32)) and np.array_equal(A["e"][a], B["e"][b]), (a, b)
+            assert A["imask"][a] == B["imask"][b] and A["tri_mask"][a] == B["tri_mask"][b]
+            assert np.array_equal(A["qlo"][a], B["qlo"][b]) and np.array_equal(A["qhi"][a], B["qhi"][b])
+            n_inner, n_tri = bin(int(A["imask"][a])).count("1"), bin(int(A["tri_mask"][a])).count("1")
+            for r in range(n_inner):
+                stack.append((int(A["child_base"][a]) + r, int(B["child_base"][b]) + r))
+            ta, tb = int(A["tri_base"][a]), int(B["tri_base"][b])
+            assert np.array_equal(prim_a[ta : ta + n_tri], prim_b[tb : tb + n_tri])
+        assert seen == len(want["nodes"])
+
+
 def test_wide_refuses_the_parity_modes(wide_pairs, gpu):
     devh = wide_pairs["room_plain"][0]
     with pytest.raises(gpu.RtError) as e:

@@ -15,9 +15,13 @@ dev.run_raytracer(1000, 1000, spp, seed=1, counters=False)
 lib.rt_debug_census(dev._h, out.ctypes.data)
 _, st = dev.run_raytracer(1000, 1000, spp, seed=1, counters=False)
 lib.rt_debug_census(dev._h, out.ctypes.data)
-names = ["load order/path/hit", "attrs + material", "4 texture samples", "alpha + direction sample", "vndf pdf + light-BVH pdf", "brdf + early exits", "terminal fold", "queue store"]
-tot = float(out[:8].sum())
-print(f"wf_shade section census, S-sponza 1000x1000x{spp}: kernel_ms {st['kernel_ms']:.2f}; share of wave cycles, lanes per stamp, stamps")
+names = ["load order/path/hit", "attrs + material", "4 texture samples", "alpha coin", "sample: VNDF", "sample: cosine", "sample: light triangle", "vndf pdf",
+         "light-BVH pdf (per loop trip)", "brdf + early exits", "terminal store", "queue store"]
+N = len(names)
+tot = float(out[:N].sum())
+lane_tot = float(out[N:2 * N].sum())
+print(f"wf_shade section census, S-sponza 1000x1000x{spp}: kernel_ms {st['kernel_ms']:.2f}; share of wave cycles and the lanes each section runs at (lane-weighted cycles / cycles)")
 for i, nm in enumerate(names):
-    print(f"  {nm:28s} {float(out[i]) / tot * 100:5.1f} %   {float(out[i]) / max(1.0, float(out[16 + i])):8.0f} cycles/stamp   lanes {float(out[8 + i]) / max(1.0, float(out[16 + i])):5.1f}   stamps {int(out[16 + i])}")
-print(f"  total {tot / max(1.0, float(out[16])):.0f} wave cycles per wave-iteration")
+    c, lc = float(out[i]), float(out[N + i])
+    print(f"  {nm:32s} {c / tot * 100:5.1f} % of wave cycles at {lc / max(1.0, c):5.1f} lanes   -> {max(0.0, c - lc / 64.0) / tot * 100:5.1f} % of the kernel is idle lanes here")
+print(f"  whole kernel: {lane_tot / tot:.1f} of 64 lanes on average")

@@ -11,7 +11,7 @@ for spec in "$@"; do
   $CC $flags -c rt_wavefront.hip -o variants/$name.w.o &
   $CC $flags -c rt_wide.hip -o variants/$name.x.o &
   wait
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/$name.so host/film.o host/png_decode.o host/jpeg_decode.o host/hdr_decode.o host/gltf_loader.o host/txt_loader.o bvh_build.o wide_build.o rt_scene.o rt_group.o rt_film.o rt_bvh_device.o variants/$name.k.o variants/$name.w.o variants/$name.x.o -lz -ldl
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/$name.so host/film.o host/png_decode.o host/jpeg_decode.o host/hdr_decode.o host/gltf_loader.o host/txt_loader.o bvh_build.o wide_build.o rt_scene.o rt_group.o rt_film.o rt_bvh_device.o rt_wide_pack.o variants/$name.k.o variants/$name.w.o variants/$name.x.o -lz -ldl
   rm -f variants/$name.k.o variants/$name.w.o variants/$name.x.o
   echo "built $name ($flags)"
 done
