@@ -166,6 +166,68 @@ def load_profile(name: str, workload_id: str, src_hash: str):
     return j, rel
 
 
+def closest_hit_kernels(mode: str):
+    """Name fragments (as rocprofv3 prints them) of the closest-hit kernels of a traversal mode: the launches bench.py times as the dominant kernel."""
+    return ("wf_extend_wide<false", "wf_extend_wide_packet<false") if MODES[mode]["wide"] else ("wf_extend<false", "wf_extend_packet<false")
+
+
+def live_pmc(child_args, mode: str, timeout_s: float = 170.0):
+    """Counter evidence for THIS run (the committed PMC summaries describe an earlier run). Three child processes of this very
+    command (headline workload only, one warm-up + one timed render) under `rocprofv3 --kernel-trace --pmc <set>`, one counter set per pass as
+    MI355X_MICROARCH.md prescribes: FETCH_SIZE, WRITE_SIZE, and the SQ set behind valu_busy / lanes_per_valu. Returns (dict, source text) or
+    (None, reason). Children are plain child processes started from a process that has initialised the GPU (fork + exec of rocprofv3, which then
+    starts python3 itself): nothing is exec'ed in place."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found on this box"
+    kernels = closest_hit_kernels(mode)
+    sets = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"], "SQ": ["SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]}
+    agg, n_disp, ms = {}, {}, {}
+    t_start = time.time()
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for tag, counters in sets.items():
+            left = timeout_s - (time.time() - t_start)
+            if left < 20:
+                return None, f"live PMC passes ran out of their {timeout_s:.0f} s budget before {tag}"
+            out_dir = os.path.join(td, tag)
+            cmd = [prof, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "--pmc", *counters, "--", sys.executable, os.path.join(ROOT, "bench.py"), *child_args]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=left)
+            except subprocess.TimeoutExpired:
+                return None, f"live PMC pass {tag} timed out"
+            if r.returncode != 0:
+                return None, f"live PMC pass {tag} failed (exit {r.returncode}): {(r.stderr or r.stdout)[-200:]!r}"
+            seen = set()
+            for f in glob.glob(os.path.join(out_dir, "*", "*counter_collection.csv")):
+                for row in csv.DictReader(open(f)):
+                    if any(k in row["Kernel_Name"] for k in kernels):
+                        agg[row["Counter_Name"]] = agg.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                        key = (tag, row["Dispatch_Id"])
+                        if key not in seen:
+                            seen.add(key)
+                            n_disp[tag] = n_disp.get(tag, 0) + 1
+                            ms[tag] = ms.get(tag, 0.0) + (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+            if not n_disp.get(tag):
+                return None, f"live PMC pass {tag}: no closest-hit dispatch in the counter file"
+    fetch = agg["FETCH_SIZE"] / n_disp["FETCH_SIZE"] * 1024.0  # KB per launch -> bytes
+    write = agg["WRITE_SIZE"] / n_disp["WRITE_SIZE"] * 1024.0
+    out = {"hbm_bytes_per_launch": 2 * fetch + write, "hbm_bytes_per_launch_fetch_x1": fetch + write, "read_requests_per_launch": fetch / 64.0,
+           "launches_counted": n_disp["FETCH_SIZE"], "avg_launch_ms_under_pmc": ms["FETCH_SIZE"] / n_disp["FETCH_SIZE"], "seconds": round(time.time() - t_start, 1)}
+    if agg.get("SQ_BUSY_CYCLES") and agg.get("SQ_INSTS_VALU"):
+        cycles_per_simd = agg["SQ_BUSY_CYCLES"] / 32.0  # one SQ per shader engine; a wave64 VALU instruction issues over 2 cycles (tools/pmc_summarize.py)
+        out["valu_busy"] = round(2.0 * agg["SQ_INSTS_VALU"] / (256 * 4) / cycles_per_simd, 4)
+        out["lanes_per_valu"] = round(agg["SQ_THREAD_CYCLES_VALU"] / agg["SQ_INSTS_VALU"], 2) if agg.get("SQ_THREAD_CYCLES_VALU") else None
+        out["wait_any_frac"] = round(agg["SQ_WAIT_ANY"] / agg["SQ_WAVE_CYCLES"], 4) if agg.get("SQ_WAVE_CYCLES") else None
+    return out, (f"measured in THIS run: child processes of the same command under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ set (separate passes, "
+                 f"{out['launches_counted']} closest-hit launches counted, {out['seconds']} s); FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md")
+
+
 def measured_stream_peak():
     """Best streaming-read rate of the box class from the committed microbenchmark record (nominal peak stays 8 TB/s)."""
     for rnd in (PROFILE_ROUND, "r02", "r01"):
@@ -286,9 +348,10 @@ class Runner:
         self.last_stats = st
         return float(self.n_pix) * self.spp * steps / elapsed / 1e6
 
-    def roofline(self):
+    def roofline(self, live=None):
         """Roofline record of the closest-hit kernel for the steps just timed. Event counters come from the instrumented kernel
-        variant on a bounded budget (<= 64 M samples) and are scaled to the step's sample count."""
+        variant on a bounded budget (<= 64 M samples) and are scaled to the step's sample count. `live`: (dict, source) from live_pmc():
+        HBM traffic and SQ figures measured by child passes of this run; they take precedence over the committed profile summaries."""
         cnt_spp = max(1, min(self.spp, (64 << 20) // max(1, self.my_pixels)))
         _, cst = self.dev.run_raytracer(self.W, self.H, cnt_spp, seed=SEED, device_fb=self.fb.data_ptr(), counters=True, global_best=self.m["gbest"], **self.shard_kw())
         scale = self.spp / cnt_spp
@@ -320,6 +383,18 @@ class Runner:
                 limiter = pj.get("limiter")
             else:
                 pmc = {"source": None, "note": pmc_source}
+        if live is not None and live[0] is not None:
+            lv = live[0]
+            traffic, traffic_x1, requests = lv["hbm_bytes_per_launch"], lv["hbm_bytes_per_launch_fetch_x1"], lv["read_requests_per_launch"]
+            request_roof = request_roof or 55.0
+            traffic_source = live[1]
+            pmc = dict(pmc or {})
+            for k in ("valu_busy", "lanes_per_valu", "wait_any_frac"):
+                if lv.get(k) is not None:
+                    pmc[k] = lv[k]
+            pmc["live"] = {k: lv[k] for k in ("launches_counted", "avg_launch_ms_under_pmc", "seconds")}
+        elif live is not None:
+            traffic_source = f"{traffic_source}; live PMC: {live[1]}"
         hbm_rate = traffic / launch_s / 1e9 if traffic else None
         request_frac = requests / launch_s / 1e9 / request_roof if requests and request_roof else None
         l1_frac = pmc.get("l1_frac") if pmc else None
@@ -451,6 +526,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: sponza, with S-10M as extra_workloads.s10m on one GPU")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"], help="weak (= auto): 64 SPP per GPU at every N; strong = BASELINE config 4 (1000 SPP in all) as the headline")
+    ap.add_argument("--live-pmc", default="auto", choices=["auto", "off"], help="auto: on one GPU, at a workload's full size, measure the headline kernel's HBM traffic and SQ "
+                    "figures with child rocprofv3 passes of this command after the timed steps (about a minute); off: quote the committed, hash-checked profiles only")
     ap.add_argument("--no-config4", action="store_true", help="skip the extra config-4 record (one 1000-SPP step after the headline)")
     ap.add_argument("--gather", default="gather", choices=["gather", "allgather"], help="torchrun flow: dist.gather to rank 0, or all_gather_into_tensor")
     ap.add_argument("--mode", default="parity", choices=sorted(MODES), help="traversal mode of the HEADLINE value (default parity; the others are reported under 'production')")
@@ -510,7 +587,11 @@ def main() -> None:
     if launcher == "group" and run.ranks_formed != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the library formed {run.ranks_formed} rank(s)")
     value = run.timed(args.steps, args.warmup)
-    roofline = run.roofline()
+    live = None
+    if args.live_pmc == "auto" and args.gpus == 1 and rank == 0 and full_size is True and not os.environ.get("RT_AMD_LIB"):
+        child = ["--workload", wl_name, "--mode", args.mode, "--bvh", args.bvh, "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--no-config4", "--live-pmc", "off", "--film", args.film]
+        live = live_pmc(child, args.mode)
+    roofline = run.roofline(live)
     roofline["packet"] = run.packet_record()
     elapsed = run.elapsed
     single = args.gpus == 1 and rank == 0

@@ -228,7 +228,7 @@ typedef struct rt_params {
     float packet_min_lanes;   /* RT_PACKET_AUTO: lanes served per packet trip below which later passes use the per-lane kernel;
                                  0 = 33 (binary tree, profiles/r02_packet.txt) / 20 (wide tree, profiles/r03_wide.txt) */
     uint32_t reserved0;       /* 0 */
-    uint64_t max_paths;       /* paths (pixel, sample) per pass of the wavefront pipeline; 0 = 64 M, capped by free device memory */
+    uint64_t max_paths;       /* paths (pixel, sample) per pass of the wavefront pipeline; 0 = 128 M, capped by free device memory */
     rt_progress_fn progress;  /* may be NULL */
     void *progress_user;
 } rt_params;
