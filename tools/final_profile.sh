@@ -1,9 +1,9 @@
 #!/usr/bin/env bash
 # tools/final_profile.sh <tag> — everything the round's profiles/ directory is made of, on the GPU box (about 15 minutes):
 # both workloads x {parity, production build} through tools/profile_round.sh (bench line, rocprofv3 --stats, FETCH/WRITE_SIZE passes, SQ/TCP/TCC
-# passes, stamped summaries) and the HBM stream microbenchmark. Then: tools/install_profiles.sh <tag> r03 copies the summaries
+# passes, stamped summaries) and the HBM stream microbenchmark. Then: tools/install_profiles.sh <tag> r04 copies the summaries
 # into profiles/. Run it AFTER the last change to the device sources: bench.py only quotes profiles whose source hash matches.
-tag=${1:-r03}
+tag=${1:-r04}
 O=gpurun_out; mkdir -p $O
 for wl in sponza s10m; do
   ./tools/profile_round.sh $wl $tag parity reference > $O/${tag}_profile_${wl}_parity.txt 2>&1; tail -2 $O/${tag}_profile_${wl}_parity.txt

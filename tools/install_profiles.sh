@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # tools/install_profiles.sh <tag> [round] — copy the summaries tools/final_profile.sh <tag> left under gpurun_out/ into profiles/<round>_*
 set -e
-tag=${1:?tag}; rnd=${2:-r03}
+tag=${1:?tag}; rnd=${2:-r04}
 cd "$(dirname "$0")/.."
 for id in sponza sponza-dev-wide s10m s10m-dev-wide; do
   for f in hbm_traffic pmc_wf_extend pmc_wf_shade pmc_wf_extend_packet bench; do

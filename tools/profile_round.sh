@@ -8,11 +8,11 @@
 # <id> = bench.py's workload_id (sponza, sponza-wide, s10m, ...). Every summary is stamped with the hash of the device sources
 # (bench.py kernel_source_hash) so a later bench run can tell whether it still describes the kernels it is running. Copy what
 # should be judged from gpurun_out/ into profiles/ (tools/install_profiles.sh).
-wl=${1:-sponza}; tag=${2:-r03}; mode=${3:-parity}; bvh=${4:-reference}
+wl=${1:-sponza}; tag=${2:-r04}; mode=${3:-parity}; bvh=${4:-reference}
 export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; mkdir -p $O
 id=$wl; [ "$bvh" = device ] && id=$wl-dev; [ "$mode" = wide ] && id=$id-wide; [ "$mode" = global ] && id=$id-gbest
 if [ "$wl" = s10m ]; then pmc_spp=8; else pmc_spp=16; fi
-extra="--workload $wl --mode $mode --bvh $bvh --no-extras"
+extra="--workload $wl --mode $mode --bvh $bvh --no-extras --no-config4 --live-pmc off"
 cpu=""; { [ "$wl" = s10m ] || [ "$mode" != parity ]; } && cpu="--no-cpu-baseline"  # the CPU leg is on the default bench line (S-sponza, parity)
 python3 $R/bench.py $extra $cpu > $O/${tag}_bench_$id.json 2> $O/${tag}_bench_$id.err; echo "bench exit $?"; tail -c 1500 $O/${tag}_bench_$id.json
 cd /tmp
