@@ -40,8 +40,20 @@ namespace {
 #endif
 #define RT_WIDE_COOP_MAX 8u /* triangles one lane contributes to a batch; more stay pending for the next one */
 
+// What a node visit needs of the ray, computed ONCE where the ray is taken from the queue (round 4: the packed node's origin is an index m on the scene
+// grid, so the ray-dependent half of every plane equation can leave the node step): on axis a the parameter of the node's plane q is
+//     t = q * ad + m * gi + c,     ad = cell / d = ids * 2^e4,   gi = g / d,   c = (grid base - o) / d,
+// and the conservative margin is folded into c: `lo` for entry planes, `hi` for exit planes. Margin: every magnitude in that sum is below
+// B = (|base - o| + 2^20 g) |1/d|, five roundings of <= 2^-24 of such magnitudes are involved -> 2^-19 B on either side (about 1e-4 of a
+// parameter unit on the bench scenes, against node extents of 0.25 and more): a box can only be entered earlier / left later than in exact arithmetic.
+struct WRay {
+    V3 lo, hi; // c -/+ margin
+    V3 gi;     // g / d
+    V3 ids;    // (1/d) * 2^e_base: a node's ad is this with the node's 4-bit exponent added to the exponent field
+};
 struct WTrav {
-    V3 o, d, idir;     // idir: 1/d with tiny components clamped (see wide_init)
+    V3 o, d;           // for the triangle tests
+    WRay w;
     uint32_t oct_inv;  // 7 ^ direction-sign octant
     uint32_t gx, gy;   // current node group: first inner child of the node | pending slots by priority (bits 31..24), inner-slot mask (bits 7..0)
     uint32_t top_x, top_y; // newest stacked group, cached in registers
@@ -51,16 +63,36 @@ struct WTrav {
     bool done;
 };
 
+// a direction component of (almost) zero would make 0 * inf = NaN in the slab terms: clamp |1/d| to 2^60. The slab then spans
+// (-huge, +huge) for an origin inside it, is empty for one outside, and the boundary case counts as inside (conservative). A component
+// beyond 2^40 (1/d below 2^-40; no unit-length direction has one) is clamped too, so that the exponent arithmetic below stays among normal floats
+// (rt_scene.cpp bounds the scene's cell exponents to match).
+DEV float wide_clamp_idir(float d, float r) {
+    const float big = 1152921504606846976.0f, small = 8.673617379884035e-19f; // 2^60, 2^-60
+    const float a = __builtin_fabsf(d);
+    return a < small ? __builtin_copysignf(big, d) : (a > 1099511627776.0f ? __builtin_copysignf(9.094947017729282e-13f, d) : r); // 2^40 -> 2^-40
+}
+DEV WRay wide_ray(const WideGrid &G, V3 o, V3 idir) {
+    WRay w;
+    const float scale = __uint_as_float((uint32_t)(G.e_base + 127) << 23); // 2^e_base
+    const float span = 1048576.0f * G.g;                                    // 2^20 g: beyond every m * g
+    const V3 c0 = mk(G.base[0] - o.x, G.base[1] - o.y, G.base[2] - o.z);
+    const V3 c = c0 * idir;
+    const V3 e = mk((__builtin_fabsf(c0.x) + span) * __builtin_fabsf(idir.x), (__builtin_fabsf(c0.y) + span) * __builtin_fabsf(idir.y),
+                    (__builtin_fabsf(c0.z) + span) * __builtin_fabsf(idir.z)) * 1.9073486328125e-06f; // 2^-19
+    w.lo = c - e;
+    w.hi = c + e;
+    w.gi = idir * G.g;
+    w.ids = idir * scale;
+    return w;
+}
+
 DEV void wide_init(WTrav &T, const DevBvh &bvh, V3 o, V3 d, V3 r) {
     T.o = o;
     T.d = d;
-    // a direction component of (almost) zero would make 0 * inf = NaN in the slab terms: clamp |1/d| to 2^60. The slab then spans
-    // (-huge, +huge) for an origin inside it, is empty for one outside, and the boundary case counts as inside (conservative).
-    const float big = 1152921504606846976.0f; // 2^60
-    T.idir.x = __builtin_fabsf(d.x) < 8.673617379884035e-19f ? __builtin_copysignf(big, d.x) : r.x;
-    T.idir.y = __builtin_fabsf(d.y) < 8.673617379884035e-19f ? __builtin_copysignf(big, d.y) : r.y;
-    T.idir.z = __builtin_fabsf(d.z) < 8.673617379884035e-19f ? __builtin_copysignf(big, d.z) : r.z;
-    const uint32_t oct = (T.idir.x < 0.0f ? 1u : 0u) | (T.idir.y < 0.0f ? 2u : 0u) | (T.idir.z < 0.0f ? 4u : 0u);
+    const V3 idir = mk(wide_clamp_idir(d.x, r.x), wide_clamp_idir(d.y, r.y), wide_clamp_idir(d.z, r.z));
+    T.w = wide_ray(bvh.grid, o, idir);
+    const uint32_t oct = (idir.x < 0.0f ? 1u : 0u) | (idir.y < 0.0f ? 2u : 0u) | (idir.z < 0.0f ? 4u : 0u);
     T.oct_inv = 7u ^ oct;
     T.gx = 0u;
     T.gy = bvh.n_wide != 0u ? 0x80000000u : 0u; // "slot oct of a node whose children start at record 0": the root, whatever oct is (imask 0)
@@ -73,21 +105,16 @@ DEV void wide_init(WTrav &T, const DevBvh &bvh, V3 o, V3 d, V3 r) {
 
 DEV float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u); } // v_cvt_f32_ubyteK
 
-// The eight slab tests of one node record against one ray: bit i of the result = the ray meets slot i's box within [EPS, tlim].
-// t = q * ad + b stands for ((p + q * cell) - o) / d. Error margin: the two products and the sum are each rounded once
-// (<= 3 half-ulps of the larger magnitude), 1/d itself is off by half an ulp: 2^-21 of (|b| + 255 |ad|) covers it 4x over.
-// The packed node's header (piece 0, rt_device_types.h): origin = grid base + m * g (exact: wide_grid.h), cell = 2^(e4 + e_base).
+// The packed node's header (piece 0, rt_device_types.h): origin index m on the scene grid, 4-bit cell exponents, slot states, base.
 struct WideHdr {
-    V3 p;      // the node's origin
-    V3 cell;   // cell sizes
+    uint32_t mx, my, mz;    // origin = grid base + m * g
+    uint32_t ex, ey, ez;    // the 4-bit cell exponents, already at the position of a float's exponent field (<< 23)
     uint32_t base, imask, tri_mask; // first inner child (16-byte unit index), inner-slot mask, leaf triangles (3 bits per slot, as WideNode::tri_mask)
 };
-DEV WideHdr wide_decode(const uint4 h, const WideGrid &G) {
+DEV WideHdr wide_decode(const uint4 h) {
     WideHdr H;
-    const uint32_t mx = h.z & 0xFFFFFu, my = __builtin_amdgcn_alignbit(h.w, h.z, 20) & 0xFFFFFu, mz = (h.w >> 8) & 0xFFFFFu;
-    H.p = mk(__builtin_fmaf((float)mx, G.g, G.base[0]), __builtin_fmaf((float)my, G.g, G.base[1]), __builtin_fmaf((float)mz, G.g, G.base[2]));
-    const uint32_t eb = (uint32_t)(G.e_base + 127);
-    H.cell = mk(__uint_as_float((((h.y >> 24) & 15u) + eb) << 23), __uint_as_float(((h.y >> 28) + eb) << 23), __uint_as_float(((h.w >> 28) + eb) << 23));
+    H.mx = h.z & 0xFFFFFu, H.my = __builtin_amdgcn_alignbit(h.w, h.z, 20) & 0xFFFFFu, H.mz = (h.w >> 8) & 0xFFFFFu;
+    H.ex = (h.y >> 1) & 0x07800000u, H.ey = (h.y >> 5) & 0x07800000u, H.ez = (h.w >> 5) & 0x07800000u;
     const uint32_t state = h.y & 0xFFFFFFu;
     uint32_t t = (state >> 2) & ~state & 0x249249u; // bit 3s: slot s holds the pattern 100 = an inner node
     H.tri_mask = state & ~(t << 2);
@@ -98,19 +125,19 @@ DEV WideHdr wide_decode(const uint4 h, const WideGrid &G) {
     return H;
 }
 
-DEV uint32_t wide_test8(const WideHdr &H, const uint4 n2, const uint4 n3, const uint4 n4, V3 o, V3 idir, float tlim) {
-    const float adx = H.cell.x * idir.x, ady = H.cell.y * idir.y, adz = H.cell.z * idir.z;
-    const float bx = (H.p.x - o.x) * idir.x, by = (H.p.y - o.y) * idir.y, bz = (H.p.z - o.z) * idir.z;
-    const float ex = __builtin_fmaf(255.0f, __builtin_fabsf(adx), __builtin_fabsf(bx)) * 4.76837158203125e-07f,
-                ey = __builtin_fmaf(255.0f, __builtin_fabsf(ady), __builtin_fabsf(by)) * 4.76837158203125e-07f,
-                ez = __builtin_fmaf(255.0f, __builtin_fabsf(adz), __builtin_fabsf(bz)) * 4.76837158203125e-07f;
-    const float bx0 = bx - ex, bx1 = bx + ex, by0 = by - ey, by1 = by + ey, bz0 = bz - ez, bz1 = bz + ez;
-    // near / far planes per axis by the direction sign: words {slots 0..3, slots 4..7}. Selected with a per-lane BIT mask (sign of 1/d smeared
-    // over the word; one v_bitop3_b32 per select), not with `cond ? a : b`: the compiler turns the latter into one v_cmp and four
-    // v_cndmask_b32_e32 reading vcc, and on gfx950 every vcc-reading VOP2 select that does not directly follow its compare holds the SIMD for
-    // ~16-23 cycles against ~3.3 for a bitwise op (tools/ubench/valu_rates.hip, profiles/r04_variants.txt item 2): 12 selects per node visit.
-    uint32_t mx = (uint32_t)((int32_t)__float_as_uint(idir.x) >> 31), my = (uint32_t)((int32_t)__float_as_uint(idir.y) >> 31),
-             mz = (uint32_t)((int32_t)__float_as_uint(idir.z) >> 31);
+// The eight slab tests of one node record against one ray: bit i of the result = the ray meets slot i's box within [EPS, tlim].
+// Plane q of axis a: t = q * ad + (m * gi + lo / hi), see WRay: two FMAs per plane pair and axis for the node-dependent constant, one FMA per plane.
+DEV uint32_t wide_test8(const WideHdr &H, const uint4 n2, const uint4 n3, const uint4 n4, const WRay &w, float tlim) {
+    const float adx = __uint_as_float(__float_as_uint(w.ids.x) + H.ex), ady = __uint_as_float(__float_as_uint(w.ids.y) + H.ey),
+                adz = __uint_as_float(__float_as_uint(w.ids.z) + H.ez);
+    const float fx = (float)H.mx, fy = (float)H.my, fz = (float)H.mz;
+    const float bx0 = __builtin_fmaf(fx, w.gi.x, w.lo.x), bx1 = __builtin_fmaf(fx, w.gi.x, w.hi.x), by0 = __builtin_fmaf(fy, w.gi.y, w.lo.y),
+                by1 = __builtin_fmaf(fy, w.gi.y, w.hi.y), bz0 = __builtin_fmaf(fz, w.gi.z, w.lo.z), bz1 = __builtin_fmaf(fz, w.gi.z, w.hi.z);
+    // near / far planes per axis by the direction sign: words {slots 0..3, slots 4..7}. Selected with a per-lane BIT mask (the sign of 1/d smeared
+    // over the word: one v_bfi_b32 per select) instead of `cond ? a : b` (one compare and four v_cndmask on vcc per axis): equally fast
+    // (profiles/r04_variants.txt item 3: only DEPENDENT back-to-back vcc selects are slow on gfx950), three compares fewer.
+    uint32_t mx = (uint32_t)((int32_t)__float_as_uint(w.ids.x) >> 31), my = (uint32_t)((int32_t)__float_as_uint(w.ids.y) >> 31),
+             mz = (uint32_t)((int32_t)__float_as_uint(w.ids.z) >> 31);
     asm volatile("" : "+v"(mx), "+v"(my), "+v"(mz)); // opaque: otherwise the masks are recognised as sign tests and the selects come back as v_cndmask on vcc
     auto pick = [](uint32_t m, uint32_t if_set, uint32_t if_clear) { return (if_set & m) | (if_clear & ~m); };
     const uint32_t xn0 = pick(mx, n3.z, n2.x), xn1 = pick(mx, n3.w, n2.y), xf0 = pick(mx, n2.x, n3.z), xf1 = pick(mx, n2.y, n3.w);
@@ -149,7 +176,7 @@ DEV uint32_t wide_leaf_tris(uint32_t l, uint32_t tri_mask) {
 
 // One node visit: take the next child of the current group (pushing the rest back if any), fetch its record and test its
 // eight boxes against [EPS, best.t]. Leaves the child's own group in (gx, gy) and its hit triangles in (tbase, tm, tall).
-template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const uint4 *blob, const WideGrid &G, STK &stk, LaneStats<STATS> &st) {
+template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const uint4 *blob, STK &stk, LaneStats<STATS> &st) {
     const uint32_t hits = T.gy;
     const uint32_t bit = 31u - (uint32_t)__clz((int)hits);
     const uint32_t rest = hits ^ (1u << bit);
@@ -166,9 +193,9 @@ template <bool STATS, class STK> DEV void wide_node_step(WTrav &T, const uint4 *
     const uint4 n0 = p[0], n2 = p[1], n3 = p[2], n4 = p[3];
     st.node();
     st.box(8);
-    const WideHdr H = wide_decode(n0, G);
+    const WideHdr H = wide_decode(n0);
     const uint32_t imask = H.imask;
-    const uint32_t h = wide_test8(H, n2, n3, n4, T.o, T.idir, T.best.t);
+    const uint32_t h = wide_test8(H, n2, n3, n4, T.w, T.best.t);
     T.gx = H.base;
     T.gy = (wide_priority(h & imask, T.oct_inv) << 24) | imask;
     T.tbase = H.base + RT_WIDE_NODE_UNITS * (uint32_t)__popc(imask); // the node's triangle records follow its inner children
@@ -272,9 +299,9 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) 
     RT_DECLARE_RING_STACK_W(stk, RT_WIDE_LDS_DEPTH, 2, s_stack, L.stack_overflow, L.stack_stride);
     const uint32_t n_in = L.counters[WF_CNT_IN];
     const uint4 *blob = reinterpret_cast<const uint4 *>(S.scene.wide);
-    const WideGrid G = S.scene.grid;
     WTrav T;
-    T.o = T.d = T.idir = mk(0.f, 0.f, 0.f);
+    T.o = T.d = mk(0.f, 0.f, 0.f);
+    T.w.lo = T.w.hi = T.w.gi = T.w.ids = mk(0.f, 0.f, 0.f);
     T.oct_inv = 0u;
     T.gx = T.gy = T.top_x = T.top_y = 0u;
     T.sp = 0;
@@ -359,7 +386,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) 
             WDG_STAMP(dg_tri);
         } else {
             if (stepper)
-                wide_node_step<STATS>(T, blob, G, stk, st);
+                wide_node_step<STATS>(T, blob, stk, st);
 #ifdef RT_DIAG_CYCLES
             dg_nodes_n += 1, dg_nodes_lanes += (unsigned long long)__popcll(sm);
 #endif
@@ -389,14 +416,16 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) 
 #ifndef RT_WIDE_PKT_CHUNK
 #define RT_WIDE_PKT_CHUNK 256u
 #endif
-template <bool STATS> __global__ __launch_bounds__(256, 8) void wf_extend_wide_packet(const DevScene S, const WfLaunch L) {
+#ifndef RT_WIDE_PKT_WAVES_PER_SIMD
+#define RT_WIDE_PKT_WAVES_PER_SIMD 6 /* 80 VGPRs: a lane carries its ray's precomputed slab constants (WRay, 12 registers); the kernel issues VALU ~80 % of the time, 6 waves feed that */
+#endif
+template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_PKT_WAVES_PER_SIMD) void wf_extend_wide_packet(const DevScene S, const WfLaunch L) {
     __shared__ uint2 s_stack_all[4][RT_MAX_STACK + 1]; // one pending group per level of the tree at most (depth <= RT_MAX_STACK)
     uint2 *s_stack = s_stack_all[threadIdx.x >> 6];
     LaneStats<STATS> st;
     const uint32_t n_in = L.counters[WF_CNT_IN];
     const uint32_t lane = threadIdx.x & 63u;
     const uint4 *blob = reinterpret_cast<const uint4 *>(S.scene.wide);
-    const WideGrid G = S.scene.grid;
     unsigned long long n_trips = 0ull, n_lanes = 0ull; // wave-uniform
     for (;;) {
         uint32_t base = 0;
@@ -408,7 +437,9 @@ template <bool STATS> __global__ __launch_bounds__(256, 8) void wf_extend_wide_p
         for (uint32_t q0 = base; q0 < base + RT_WIDE_PKT_CHUNK && q0 < n_in; q0 += 64u) { // wave-uniform
             const uint32_t jq = q0 + lane;
             const bool have = jq < n_in;
-            V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f), idir = mk(1.f, 1.f, 1.f);
+            V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);
+            WRay w = wide_ray(S.scene.grid, o, mk(1.f, 1.f, 1.f));
+            uint32_t my_oct_inv = 7u;
             Hit best = Hit{RT_NONE, 0.f, 0.f, -RT_INF}; // a lane without a ray: an empty [EPS, -inf] range meets no box
             if (have) {
                 const uint32_t j = L.order ? L.order[jq] : jq;
@@ -416,11 +447,10 @@ template <bool STATS> __global__ __launch_bounds__(256, 8) void wf_extend_wide_p
                 const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
                 WTrav T;
                 wide_init(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r2.x, r2.y, r2.z));
-                o = T.o, d = T.d, idir = T.idir;
+                o = T.o, d = T.d, w = T.w, my_oct_inv = T.oct_inv;
                 best.t = RT_INF;
             }
-            const uint32_t oct = (idir.x < 0.0f ? 1u : 0u) | (idir.y < 0.0f ? 2u : 0u) | (idir.z < 0.0f ? 4u : 0u);
-            const uint32_t oct_inv = 7u ^ (uint32_t)__builtin_amdgcn_readfirstlane((int)oct); // lane 0 of the packet always has a ray
+            const uint32_t oct_inv = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_oct_inv); // lane 0 of the packet always has a ray
             uint32_t gx = 0u, gy = S.scene.n_wide != 0u ? 0x80000000u : 0u; // wave-uniform
             int sp = 0;
             for (;;) {
@@ -449,9 +479,9 @@ template <bool STATS> __global__ __launch_bounds__(256, 8) void wf_extend_wide_p
                 const U4v v0 = p[0], v2 = p[1], v3 = p[2], v4 = p[3];
                 const uint4 n0 = make_uint4(v0.x, v0.y, v0.z, v0.w), n2 = make_uint4(v2.x, v2.y, v2.z, v2.w), n3 = make_uint4(v3.x, v3.y, v3.z, v3.w),
                             n4 = make_uint4(v4.x, v4.y, v4.z, v4.w);
-                const WideHdr H = wide_decode(n0, G); // wave-uniform: scalar arithmetic
+                const WideHdr H = wide_decode(n0); // wave-uniform: scalar arithmetic
                 const uint32_t imask = H.imask;
-                const uint32_t h = wide_test8(H, n2, n3, n4, o, idir, best.t);
+                const uint32_t h = wide_test8(H, n2, n3, n4, w, best.t);
                 if (have) {
                     st.node();
                     st.box(8);

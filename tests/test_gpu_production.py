@@ -424,6 +424,23 @@ def test_wide_on_tiny_scenes(gpu, oracle, sg, n_tris):
         orc.close()
 
 
+def test_wide_build_refuses_scenes_outside_its_exponent_range(gpu, sg):
+    """The packed wide node keeps cell exponents in 4 bits above a scene base and the kernels add them to a float's exponent field (rt_wide.hip, WRay):
+    sound while the scene's largest cell exponent lies in [-60, 44]. Outside, rt_create refuses RT_BUILD_WIDE (RT_ERR_UNSUPPORTED) instead of building a
+    tree whose arithmetic could leave the normal floats; the parity build of the same scene is created as before."""
+    for scale_log2 in (60, -70):
+        sc = sg.room_scene(200, seed=78, n_lights=2, n_materials=4, tex_size=0)
+        k = np.float32(2.0) ** np.float32(scale_log2)
+        sc.positions = (sc.positions * k).astype(np.float32)
+        sc.camera.position = (np.asarray(sc.camera.position, dtype=np.float32) * k).astype(np.float32)
+        assert np.isfinite(sc.positions).all() and (sc.positions != 0).any()
+        for kw in (dict(wide=True), dict(wide=True, device_bvh=True)):
+            with pytest.raises(gpu.RtError) as e:
+                gpu.DeviceScene(sc, **kw)
+            assert e.value.code == 8 and "exponent range" in str(e.value), (scale_log2, kw, str(e.value))
+        gpu.DeviceScene(sc).close()
+
+
 @pytest.mark.parametrize("scale_log2", [36, 20, -8])
 def test_production_build_at_extreme_scales(gpu, oracle, sg, scale_log2):
     """The same room scaled by 2^36, 2^20 and 2^-8: every production build against the oracle — the superset contract on 12 000 rays, every
