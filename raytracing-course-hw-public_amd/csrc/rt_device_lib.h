@@ -1232,6 +1232,16 @@ DEV bool ticket_take(uint32_t *counters, uint32_t n_in, uint32_t chunk, TicketSt
 //   push     : a scattering event happened: push (emission, scl) and continue with the ray (nro, nrd)
 //   neither  : stochastic alpha pass-through (:559-561): continue with (nro, nrd), no frame
 // RNG draw order is the reference's: alpha coin, technique coin, then the sampler's own draws.
+// Which sampler the NEXT shade() of a path will run, from the generator state the path record stores (taken by value): the alpha coin
+// is drawn first whatever the material (:559), the technique coin second (:565), mix_dist's pick third (:386). 0 VNDF, 1 cosine, 2 light
+// triangle. A scheduling hint for wf_shade's lane assignment only: a miss or an alpha pass-through never gets that far, and nothing
+// computed depends on it.
+template <class R> DEV uint32_t next_shade_class(R rng, bool has_lights) {
+    (void)uniform_real(rng, 0.0f, 1.0f);
+    if (uniform_real(rng, 0.0f, 1.0f) <= VNDF_FACTOR)
+        return 0u;
+    return (!has_lights || rng.below(2) == 0u) ? 1u : 2u;
+}
 struct ShadeResult {
     bool terminal, push;
     V3 term, emission, scl, nro, nrd;

@@ -193,13 +193,16 @@ struct alignas(64) WfPath {
     float o[3];
     float dx;
     float dy, dz;
-    uint32_t path;  // path id within the pass = index into fold / sample_out
+    uint32_t path;  // path id within the pass = index into fold / sample_out (& WF_ORDER_SLOT_MASK); bits 30-31: the sampler class of the path's
+                    //   next shade() (next_shade_class), a scheduling hint for wf_shade
     uint32_t depth; // low 16 bits: remaining trace_ray budget (raytracer.h:596); high 16 bits: pending shade() frames
     float r[3];     // 1 / d, IEEE division, computed where the ray is made (wf_generate / wf_shade are latency bound; wf_extend,
     uint32_t fast;  //   the issue-bound kernel, just loads it) + the per-ray half of div_exact_fast's preconditions
     uint32_t s[4];  // xoshiro128++ state
 };
 static_assert(sizeof(WfPath) == 64, "WfPath must be 64 bytes");
+#define WF_ORDER_SLOT_MASK 0x3FFFFFFFu /* WfLaunch::order: queue slot; max_paths <= 2^30 */
+#define WF_ORDER_CLASS_SHIFT 30
 struct alignas(16) WfHit { // 16 B: closest hit of the ray in the same queue slot
     uint32_t k;            // DevTri index (scene-BVH order) or RT_NONE
     float b, c, t;
@@ -265,7 +268,8 @@ struct WfLaunch {
                              // that wrote paths_in (0: paths_in is dense, as wf_generate leaves it)
     uint32_t *stripes;       // WF_STRIPE_BUF_WORDS: the sub-queue fill counters of the running wf_shade, then run_start[] of paths_in
     void *diag;              // development census (-DRT_DIAG), 32 x u64, else unused
-    const uint32_t *order;   // optional: position q processes queue slot order[q] (coherence sort; extend AND shade); null = identity
+    const uint32_t *order;   // optional: position q processes queue slot order[q] & WF_ORDER_SLOT_MASK (coherence sort; extend AND shade); null = identity.
+                             // Bits 30-31 carry the ray's NEXT sampler class (top bits of WfPath's path word) through the sort: wf_shade's lane assignment reads them
     uint32_t *sort_keys[2];  // sort workspace: keys / slot indices, double buffered
     uint32_t *sort_vals[2];
     void *sort_temp;
@@ -274,6 +278,7 @@ struct WfLaunch {
     unsigned long long *packet_census; // [2] device: trips, lanes served (summed over the launch's waves)
     uint32_t global_best;    // 0: the reference's traversal order and pruning (parity mode); 1: prune against the global best
                              // (RT_FLAG_GLOBAL_BEST, production traversal: a subset of the reference's node visits)
+    uint32_t order_classed;  // `order` came through the ray-order sort and carries the class bits; 0: identity-like order (no sort ran), slots only
     uint32_t sort_mode;      // 0 off, 1 cell+octant, 2 coarse cell + direction code, 3 octant+cell, 4 cell+octant+sub-cone (default) (RT_WF_SORT)
     size_t sort_temp_bytes;
     DevStats *stats;         // may be null

@@ -48,6 +48,9 @@ namespace {
 #define RT_SHADE_BLOCKS_PER_CU 8 /* grid of the grid-stride kernels (wf_shade, wf_extend_prims) */
 #endif
 #ifndef RT_SHADE_LDS_DEPTH
+#ifndef RT_SHADE_RECLASS
+#define RT_SHADE_RECLASS 1 /* wf_shade hands its block's hits to the lanes sorted by sampler class */
+#endif
 #define RT_SHADE_LDS_DEPTH 4 /* only the light-BVH traversal of bvh_mix_dist::pdf uses a stack in wf_shade */
 #endif
 using ShadeStack = StackMemT<RT_SHADE_LDS_DEPTH>;
@@ -93,7 +96,7 @@ template <bool STATS> __global__ __launch_bounds__(256) void wf_generate(const D
         V3 rd = norm(sx * cam_right - sy * cam_up + 1.0f * cam_fwd);
         float4 *rq = reinterpret_cast<float4 *>(L.paths_in + i);
         rq[0] = make_float4(cam_pos.x, cam_pos.y, cam_pos.z, rd.x);
-        rq[1] = make_float4(rd.y, rd.z, __uint_as_float(i), __uint_as_float(L.ray_depth)); // path id; full budget, no pending frames
+        rq[1] = make_float4(rd.y, rd.z, __uint_as_float(i | (next_shade_class(rng, S.lights.n_tris != 0) << WF_ORDER_CLASS_SHIFT)), __uint_as_float(L.ray_depth)); // path id (+ class); full budget, no pending frames
         rq[2] = make_float4(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z, __uint_as_float(ray_fast_ok_ray(cam_pos, rd) ? 1u : 0u));
         *reinterpret_cast<uint4 *>(rq + 3) = make_uint4(rng.g.s[0], rng.g.s[1], rng.g.s[2], rng.g.s[3]);
         st.cast(); // ray_depth >= 1: trace_ray casts (raytracer.h:600)
@@ -241,7 +244,7 @@ template <bool STATS, bool GB> __global__ __launch_bounds__(256, RT_EXT_WAVES_PE
             const uint32_t avail = q_hi - q_lo;
             if (idle && rank < avail) {
                 const uint32_t jq = q_lo + rank;
-                const uint32_t j = L.order ? L.order[jq] : jq; // coherence-sorted processing order
+                const uint32_t j = L.order ? L.order[jq] & WF_ORDER_SLOT_MASK : jq; // coherence-sorted processing order
                 const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
                 const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
                 slot = jq; // the hit goes to the queue POSITION (see WfLaunch::hits)
@@ -376,7 +379,7 @@ template <bool STATS, bool GB> __global__ __launch_bounds__(256, RT_EXT_WAVES_PE
             const bool have = jq < n_in;
             T.cur = T_DONE;
             if (have) {
-                const uint32_t j = L.order ? L.order[jq] : jq;
+                const uint32_t j = L.order ? L.order[jq] & WF_ORDER_SLOT_MASK : jq;
                 const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
                 const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
                 trav_init_stored<GB>(T, S.scene, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r2.x, r2.y, r2.z), __float_as_uint(r2.w) != 0u);
@@ -454,7 +457,7 @@ template <bool STATS, bool GB> __global__ __launch_bounds__(256, RT_EXT_WAVES_PE
 __global__ __launch_bounds__(256) void wf_extend_prims(const DevScene S, const WfLaunch L) {
     const uint32_t n_in = L.counters[WF_CNT_IN];
     for (uint32_t jq = blockIdx.x * blockDim.x + threadIdx.x; jq < n_in; jq += gridDim.x * blockDim.x) {
-        const uint32_t j = L.order ? L.order[jq] : jq;
+        const uint32_t j = L.order ? L.order[jq] & WF_ORDER_SLOT_MASK : jq;
         const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
         const float4 r0 = rq[0], r1 = rq[1];
         const float4 hq = *reinterpret_cast<const float4 *>(L.hits + jq);
@@ -475,6 +478,9 @@ template <bool STATS, bool LIGHTS_LDS, bool ENV> __global__ __launch_bounds__(25
     __shared__ float s_gam[256];
     __shared__ uint32_t s_stack[STACK_LDS_DWORDS_FOR(RT_SHADE_LDS_DEPTH)];
     __shared__ float4 s_lights[LIGHTS_LDS ? RT_SHADE_LIGHTS_F4 : 1];
+#if RT_SHADE_RECLASS
+    __shared__ uint2 s_perm[4][256]; // per wave: (queue position, queue slot) of its 256 positions, sorted by sampler class
+#endif
     LightTabs LT = light_tabs_global(S);
     if (LIGHTS_LDS) {
         const uint32_t n_node_f4 = 4u * (S.lights.lds_inner - 1u), n_tri_f4 = 3u * S.lights.n_tris;
@@ -500,21 +506,19 @@ template <bool STATS, bool LIGHTS_LDS, bool ENV> __global__ __launch_bounds__(25
     const bool has_lights = S.lights.n_tris != 0; // raytracer.h:449-453
     const uint32_t n_in = L.counters[WF_CNT_IN];
     const uint32_t n_slots = (n_in + 63u) >> 6; // wave slots of this launch: positions 64w .. 64w+63
-    const uint32_t stride = gridDim.x * blockDim.x;
-    // wave-uniform trip count: ballots below must see the whole wave
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n_in; base += stride) {
-        const uint32_t jq = base + threadIdx.x; // queue position: where wf_extend left this ray's hit
+    // one shade() level for the hit at queue position jq (the ray in queue slot j), as the lanes of one wave; `wave_slot` is the wave slot
+    // (64 positions) this trip stands for: survivors go to the sub-queue of that slot (rt_device_types.h, WF_STRIPES)
+    auto shade_wave = [&](const uint32_t jq, const uint32_t j, const uint32_t wave_slot) {
         const bool active = jq < n_in;
         bool survive = false;
         float4 nr0 = make_float4(0.f, 0.f, 0.f, 0.f), nr1 = nr0, nr2 = nr0;
         uint4 nrng = make_uint4(0u, 0u, 0u, 0u);
         if (active) {
-            const uint32_t j = L.order ? L.order[jq] : jq;
             const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
             const float4 r0 = rq[0], r1 = rq[1];
             const uint4 p0 = *reinterpret_cast<const uint4 *>(rq + 3);
             const float4 hq = *reinterpret_cast<const float4 *>(L.hits + jq);
-            const uint32_t path = __float_as_uint(r1.z);
+            const uint32_t path = __float_as_uint(r1.z) & WF_ORDER_SLOT_MASK; // the top bits: this shade()'s sampler class (lane assignment above)
             Rng<RT_RNG_DEVICE> rng;
             rng.g.s[0] = p0.x, rng.g.s[1] = p0.y, rng.g.s[2] = p0.z, rng.g.s[3] = p0.w;
             uint32_t depth_left = __float_as_uint(r1.w) & 0xFFFFu, nb = __float_as_uint(r1.w) >> 16;
@@ -548,7 +552,7 @@ template <bool STATS, bool LIGHTS_LDS, bool ENV> __global__ __launch_bounds__(25
                 survive = true;
                 st.cast();
                 nr0 = make_float4(sr.nro.x, sr.nro.y, sr.nro.z, sr.nrd.x);
-                nr1 = make_float4(sr.nrd.y, sr.nrd.z, __uint_as_float(path), __uint_as_float(depth_left | (nb << 16)));
+                nr1 = make_float4(sr.nrd.y, sr.nrd.z, __uint_as_float(path | (next_shade_class(rng, has_lights) << WF_ORDER_CLASS_SHIFT)), __uint_as_float(depth_left | (nb << 16)));
                 nr2 = make_float4(1.0f / sr.nrd.x, 1.0f / sr.nrd.y, 1.0f / sr.nrd.z, __uint_as_float(ray_fast_ok_ray(sr.nro, sr.nrd) ? 1u : 0u));
                 nrng = make_uint4(rng.g.s[0], rng.g.s[1], rng.g.s[2], rng.g.s[3]);
             }
@@ -560,7 +564,7 @@ template <bool STATS, bool LIGHTS_LDS, bool ENV> __global__ __launch_bounds__(25
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             uint32_t obase = 0;
             const int leader = __ffsll((long long)m) - 1;
-            const uint32_t stripe = (uint32_t)__builtin_amdgcn_readfirstlane((int)(jq >> 6)) % WF_STRIPES;
+            const uint32_t stripe = /* the wave's own slot: a sub-queue holds what ITS slots can emit */ (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_slot) % WF_STRIPES;
             if ((int)(threadIdx.x & 63u) == leader)
                 obase = wf_stripe_base(stripe, n_slots) + atomicAdd(L.stripes + stripe * WF_STRIPE_WORDS, (uint32_t)__popcll(m));
             obase = __shfl(obase, leader);
@@ -573,7 +577,58 @@ template <bool STATS, bool LIGHTS_LDS, bool ENV> __global__ __launch_bounds__(25
             }
         }
         SD_STAMP(SD_STORE);
+    };
+#if RT_SHADE_RECLASS
+    // Which of shade()'s three samplers a hit runs is decided by its path's next draws alone (alpha coin, technique coin, mix pick:
+    // raytracer.h:559,565,386): whoever wrote the path record left that class in the top bits of its path word, and the ray-order pass carried it along
+    // in the top bits of `order`. A WAVE takes 256 queue positions at a time and hands them to its lanes sorted by class (a counting sort
+    // over indices through the wave's own LDS window, before anything else is loaded, no block barrier): of its four trips one or two run
+    // a single sampler and the others two instead of all three, and the rays aimed at a light walk the light BVH of bvh_mix_dist::pdf
+    // side by side. Every wave still gets every class, so the waves of a block stay balanced. Which lane shades a hit changes no result.
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    // A queue too short to give every wave of the grid such a window is shaded 64 positions at a time (more waves, no reordering), and so
+    // is one no sort ran over (primary rays; RT_SORT_OFF; the wide tree of a cache-resident scene): fetching the class from the records
+    // ahead of the shading costs that kernel 6 % (measured, profiles/r04_variants.txt item 11); in the sort's payload it is free.
+    const uint32_t win = (L.order_classed && n_in >= gridDim.x * 1024u) ? 256u : 64u;
+    for (uint32_t wbase = (blockIdx.x * 4u + wv) * win; wbase < n_in; wbase += gridDim.x * 4u * win) { // wave-uniform
+        uint32_t slot_of[4], cls[4], before[3] = {0u, 0u, 0u}, within[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const uint32_t jq = wbase + 64u * q + lane;
+            slot_of[q] = jq, cls[q] = 3u; // class 3: the positions behind the queue's (or the window's) end
+            if (64u * q < win && jq < n_in) {
+                const uint32_t v = L.order ? L.order[jq] : jq;
+                slot_of[q] = v & WF_ORDER_SLOT_MASK, cls[q] = v >> WF_ORDER_CLASS_SHIFT;
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) { // position inside the class: the class's members in earlier quarters, then in lower lanes
+            const unsigned long long b0 = __ballot(cls[q] == 0u), b1 = __ballot(cls[q] == 1u), b2 = __ballot(cls[q] == 2u);
+            const unsigned long long mine = cls[q] == 0u ? b0 : cls[q] == 1u ? b1 : cls[q] == 2u ? b2 : ~(b0 | b1 | b2);
+            const uint32_t seen = cls[q] == 0u ? before[0] : cls[q] == 1u ? before[1] : cls[q] == 2u ? before[2] : 64u * q - before[0] - before[1] - before[2];
+            within[q] = seen + __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+            before[0] += (uint32_t)__popcll(b0), before[1] += (uint32_t)__popcll(b1), before[2] += (uint32_t)__popcll(b2);
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const uint32_t start = cls[q] == 0u ? 0u : cls[q] == 1u ? before[0] : cls[q] == 2u ? before[0] + before[1] : before[0] + before[1] + before[2];
+            s_perm[wv][start + within[q]] = make_uint2(wbase + 64u * q + lane, slot_of[q]);
+        }
+        __builtin_amdgcn_wave_barrier(); // the wave's LDS operations complete in order: its reads below see the writes above
+        const uint32_t n_here = n_in - wbase < win ? n_in - wbase : win;
+        for (uint32_t sub = 0; 64u * sub < n_here; ++sub) {
+            const uint2 pj = s_perm[wv][64u * sub + lane];
+            shade_wave(pj.x, pj.y, (wbase >> 6) + sub);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
+#else
+    // wave-uniform trip count: the ballots in shade_wave must see the whole wave
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n_in; base += gridDim.x * blockDim.x) {
+        const uint32_t jq = base + threadIdx.x; // queue position: where wf_extend left this ray's hit
+        shade_wave(jq, jq < n_in ? (L.order ? L.order[jq] & WF_ORDER_SLOT_MASK : jq) : 0u, jq >> 6);
+    }
+#endif
 #ifdef RT_DIAG_SHADE
     __syncthreads();
     if (threadIdx.x < 4u * SD_N && L.diag) { // census words 0..11: wave cycles per section, 12..23: lane-weighted cycles (summed over waves)
@@ -622,12 +677,13 @@ __global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLa
                     k += step;
             pos = wf_stripe_base(k, n_slots) + (j - s_run[k]);
         }
-        if (direct) {
+        const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + pos);
+        if (direct) { // no record is read here: WfLaunch::order_classed = 0
             L.sort_vals[1][j] = pos;
             continue;
         }
-        const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + pos);
         const float4 r0 = rq[0], r1 = rq[1];
+        const uint32_t val = pos | (__float_as_uint(r1.z) & ~WF_ORDER_SLOT_MASK); // the class bits of the path word ride along above the slot (WfLaunch::order)
         const float fx = (r0.x - S.bounds_lo[0]) * S.bounds_inv[0], fy = (r0.y - S.bounds_lo[1]) * S.bounds_inv[1], fz = (r0.z - S.bounds_lo[2]) * S.bounds_inv[2];
         const uint32_t cx = (uint32_t)fminf(fmaxf(fx * 64.0f, 0.0f), 63.0f), cy = (uint32_t)fminf(fmaxf(fy * 64.0f, 0.0f), 63.0f), cz = (uint32_t)fminf(fmaxf(fz * 64.0f, 0.0f), 63.0f);
         const uint32_t morton = spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
@@ -656,7 +712,7 @@ __global__ __launch_bounds__(256) void wf_sort_keys(const DevScene S, const WfLa
             key = (oct << 24) | (m21 << 3) | sub;
         }
         L.sort_keys[0][j] = key;
-        L.sort_vals[0][j] = pos;
+        L.sort_vals[0][j] = val;
     }
 }
 
@@ -817,7 +873,7 @@ hipError_t launch_wavefront_cast(const DevScene &S, WfLaunch L, const float *ray
     if (e != hipSuccess)
         return e;
     L.n_paths = n;
-    L.order = nullptr;
+    L.order = nullptr, L.order_classed = 0u;
     L.packet_census = nullptr;
     const int blocks = (int)((n + 255u) / 256u);
     WF_LAUNCH(wf_from_rays, dim3(blocks), block, 0, stream, L, rays, n);
@@ -863,7 +919,7 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
     uint32_t bound = L.n_paths; // upper bound of the queue entering the bounce about to be launched
     bool census_pending = false; // the packet census of bounce 0 is on its way to the pinned words (event 0)
     for (uint32_t b = 0; b < L.ray_depth; ++b) {
-        L.order = nullptr; // primary rays: dense and coherent as generated
+        L.order = nullptr, L.order_classed = 0u; // primary rays: dense and coherent as generated
         if (b > 0) {
             if (census_pending && b == 2) { // bounce 0's census: its copy is two bounces behind the queue head by now
                 if ((e = hipEventSynchronize(hs->events[0])) != hipSuccess)
@@ -889,6 +945,7 @@ hipError_t launch_wavefront_pass(const DevScene &S, WfLaunch L, bool stats, int 
                     return se;
             }
             L.order = L.sort_vals[1];
+            L.order_classed = sort ? 1u : 0u;
         }
         // time the dominant kernel per launch (bench.py roofline): HIP events on the launch stream, taken from the scene's
         // pool (created once, reused by every render)

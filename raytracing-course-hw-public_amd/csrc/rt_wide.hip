@@ -336,7 +336,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_WAVES_PER_SIMD) 
             const uint32_t avail = q_hi - q_lo;
             if (idle && rank < avail) {
                 const uint32_t jq = q_lo + rank;
-                const uint32_t j = L.order ? L.order[jq] : jq;
+                const uint32_t j = L.order ? L.order[jq] & WF_ORDER_SLOT_MASK : jq;
                 const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
                 const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
                 slot = jq;
@@ -442,7 +442,7 @@ template <bool STATS> __global__ __launch_bounds__(256, RT_WIDE_PKT_WAVES_PER_SI
             uint32_t my_oct_inv = 7u;
             Hit best = Hit{RT_NONE, 0.f, 0.f, -RT_INF}; // a lane without a ray: an empty [EPS, -inf] range meets no box
             if (have) {
-                const uint32_t j = L.order ? L.order[jq] : jq;
+                const uint32_t j = L.order ? L.order[jq] & WF_ORDER_SLOT_MASK : jq;
                 const float4 *rq = reinterpret_cast<const float4 *>(L.paths_in + j);
                 const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
                 WTrav T;

@@ -119,7 +119,7 @@ for kern, short in ((("wf_extend_wide<false",) if mode == "wide" else ("wf_exten
                         f"L2 hit {d.get('l2_hit')}; not HBM bandwidth (see hbm_frac)")
         if d.get("l1_frac") is not None and d["l1_frac"] >= 0.6:
             d["limiter"] = (f"vector-L1 access rate: {d['l1_accesses_per_clk_per_cu']} tag accesses per clock per CU = {d['l1_frac']:.2f} of the measured 0.98 roof "
-                            f"({'5 accesses per 80-B wide node' if mode == 'wide' else '4 accesses per 64-B node'} per lane), {d.get('l1_pending_stall_frac', 0) * 100:.0f} % of L1 cycles stalled on pending misses; "
+                            f"({'4 accesses per packed 64-B wide node' if mode == 'wide' else '4 accesses per 64-B node'} per lane), {d.get('l1_pending_stall_frac', 0) * 100:.0f} % of L1 cycles stalled on pending misses; "
                             f"VALU issue {vb * 100:.0f} % at {la} of 64 lanes, waves waiting {wa * 100 if wa else 0:.0f} %, L1 hit {d.get('l1_hit')}, L2 hit {d.get('l2_hit')}; "
                             "not HBM bandwidth (see hbm_frac)")
     path = os.path.join(O, f"{tag}_pmc_{short}_{wl}.json")
