@@ -3,7 +3,8 @@ against the CPU oracle at full scene size, plus the size-independent properties 
 
 The oracle cannot render 4 M pixels of this scene in seconds, so the pixel comparison takes every 64th 256-pixel span of
 the 2048x2048 image (65 536 pixels spread over the whole frame, shard_count = 64) at 1 SPP; hit records are compared on
-20 000 random rays; the rest are properties that need no oracle (wavefront == megakernel, union of 8 shards == single
+20 000 random rays; config 5's own depth (256 SPP, 1.07e9 samples) is rendered whole and two of its spans are recomputed by the
+oracle at all 256 samples; the rest are properties that need no oracle (wavefront == megakernel, union of 8 shards == single
 render, pass splitting). RT_TEST_S10M_TRIANGLES overrides the triangle count for a quicker local run.
 """
 import os
@@ -97,6 +98,20 @@ def test_s10m_full_size_parity_and_properties(gpu, oracle, sg):
                 del wfb32
             wd.close()
         del pfb32
+        # BASELINE config 5 at its own depth: 256 SPP = 1.07e9 samples on one GPU, eight sample passes of 32 SPP (128 M paths each) whose partial sums
+        # continue in sample order (raytracer.h:621-626); two 256-pixel spans recomputed by the oracle at the full 256 SPP must match bit for bit
+        if n >= 10_000_000:
+            fb256, st256 = dev.run_raytracer(W, H, 256, seed=0xC5)
+            assert st256["samples"] == W * H * 256 and st256["passes"] == 8
+            n_spans = W * H // 256
+            for span in (4321, 12345):
+                sfb = np.full((H, W, 3), -1.0, dtype=np.float32)
+                orc.run_raytracer(W, H, 256, seed=0xC5, shard_index=span, shard_count=n_spans, shard_block=256, out=sfb)
+                mine = sfb.reshape(-1, 3)[:, 0] != -1.0
+                assert int(mine.sum()) == 256
+                assert np.array_equal(fb256.reshape(-1, 3)[mine].view(np.uint32), sfb.reshape(-1, 3)[mine].view(np.uint32)), f"config 5 at 256 SPP: span {span} differs from the oracle"
+            print(f"[S-10M] config 5 (2048x2048x256) on one GPU: {st256['passes']} passes, {W * H * 256 / st256['kernel_ms'] / 1e3:.1f} Msamples/s device time; 2 spans x 256 SPP bit-equal to the oracle")
+            del fb256
         t_ref = dev.build_times()
         print(f"[S-10M] host reference-topology build {t_ref['build_ms'] / 1e3:.2f} s; device LBVH build {t_lb['build_ms']:.1f} ms (+ upload {t_lb['upload_ms']:.0f} ms)")
     finally:
