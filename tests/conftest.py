@@ -106,6 +106,11 @@ SCENE000 = os.path.join(ROOT, "tests", "golden", "txt", "scene-000.txt")  # BASE
                                                                           # reference's sample_data/scene-000.txt)
 
 
+PRACTICE3_5 = os.path.join(ROOT, "tests", "golden", "txt", "practice3_5.txt")  # BASELINE config 2's kind of scene file (a data fixture: the content of the
+                                                                                # reference's sample_data/homebrew_primitives/practice3_5.txt: 512x512, 64 SPP,
+                                                                                # a Cornell box of 5 PLANEs, 2 BOXes (one emissive) and an ELLIPSOID)
+
+
 def scene000_box_gltf(rt, sg, out_dir, yfov=1.2):
     """The triangles of scene-000.txt's BOX (the part of config 1 the reference at HEAD can still render: it has no ELLIPSOID / PLANE and no
     scene-txt parser) exported as glTF for the reference binary: same 12 triangles and material, camera at the file's position looking down -z,

@@ -126,6 +126,44 @@ def test_config2_primitives_only_512x512(gpu, oracle, tmp_path):
         orc.close()
 
 
+def test_config2_practice3_5_through_the_hip_path(gpu, oracle, tmp_path):
+    """BASELINE config 2 on one of the files it names: sample_data/homebrew_primitives/practice3_5.txt (committed as tests/golden/txt/practice3_5.txt:
+    a Cornell box of 5 PLANEs, an emissive BOX, a rotated BOX and an ELLIPSOID), at the file's own 512x512, 64 SPP, ray depth 6, through librt_amd.so:
+    (a) the CLI writes the oracle's PPM; (b) the device-RNG framebuffer (16.8 M samples) and every event counter equal the oracle's, in both schedules,
+    and the device film's bytes equal the host film of the oracle's image; (c) reference-RNG mode equals the oracle at 8 SPP; (d) hit records on 20 000 rays."""
+    from conftest import PRACTICE3_5
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev, orc, ls = _pair(gpu, oracle, PRACTICE3_5)
+    try:
+        info, a = ls.info(), ls.arrays()
+        W, H, SPP = info["width"], info["height"], info["samples"]
+        assert (W, H, SPP, int(a["ray_depth"])) == (512, 512, 64, 6) and a["positions"].shape[0] == 24 and [p["kind"] for p in a["primitives"]] == [2, 2, 2, 2, 2, 1]
+        ofb, ost = orc.run_raytracer(W, H, SPP, seed=23)
+        out = tmp_path / "c2.ppm"
+        subprocess.check_call([os.path.join(root, "run.sh"), PRACTICE3_5, str(W), str(H), str(SPP), str(out)], env=dict(os.environ, RT_RNG_MODE="device", RT_SEED="23", RT_DEVICE="0"))
+        assert np.array_equal(oracle.read_ppm(str(out)), oracle.tonemap(ofb))
+        for kw in ({}, {"megakernel": True}):
+            gfb, gst = dev.run_raytracer(W, H, SPP, seed=23, counters=True, **kw)
+            assert np.array_equal(gfb.view(np.uint32), ofb.view(np.uint32)), (kw, int((gfb != ofb).any(axis=2).sum()))
+            for k in COUNTERS:
+                assert gst[k] == ost[k], (k, kw)
+        assert ost["samples"] == W * H * SPP and ost["casts"] > 3 * ost["samples"]  # a closed box: paths live for several bounces
+        img, _ = dev.run_raytracer_rgb8(W, H, SPP, seed=23)
+        assert np.array_equal(img, oracle.tonemap(ofb))
+        rfb, _ = dev.run_raytracer(W, H, 8, rng_mode=gpu.RT_RNG_REFERENCE)
+        orf, _ = orc.run_raytracer(W, H, 8, rng_mode=gpu.RT_RNG_REFERENCE)
+        assert np.array_equal(rfb.view(np.uint32), orf.view(np.uint32))
+        rays = _rays(8, 20000, -4.5, 4.5)
+        gp, gb = dev.cast_rays(rays)
+        op, ob = orc.cast_rays(rays)
+        assert np.array_equal(gp, op) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+        assert (gp != 0xFFFFFFFF).mean() > 0.7 and (gp < 24).sum() > 500 and (gp == 24 + 5).sum() > 200  # (the room is open towards the camera) boxes and the ellipsoid win rays
+    finally:
+        dev.close()
+        orc.close()
+
+
 def test_config1_scene000_through_the_hip_path(gpu, sg, oracle, tmp_path):
     """BASELINE config 1: sample_data/scene-000.txt (committed as tests/golden/txt/scene-000.txt: ELLIPSOID + PLANE + BOX), 256x256, 4 SPP,
     through librt_amd.so. (a) the CLI, `run.sh scene-000.txt 256 256 4 out.ppm`, writes the oracle's PPM in both RNG modes; (b) device-RNG

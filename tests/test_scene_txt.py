@@ -195,6 +195,24 @@ def test_analytic_primitives_self_consistency(rt, oracle):
     assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32)) and np.isfinite(f1).all() and s1["casts"] == s2["casts"]
 
 
+def test_config2_fixture_is_the_reference_file_and_renders(rt, oracle):
+    """BASELINE config 2 names sample_data/homebrew_primitives (spheres / boxes, 512x512, 64 SPP). The committed fixture is one of those files,
+    practice3_5.txt, byte for byte (checked where /root/reference exists); it parses to 24 BOX triangles + 6 analytic primitives with the file's
+    own size, depth and sample count, and the CPU oracle renders it (a closed, lit Cornell box: finite, not black)."""
+    from conftest import PRACTICE3_5
+
+    ref_file = "/root/reference/sample_data/homebrew_primitives/practice3_5.txt"
+    if os.path.exists(ref_file):
+        assert open(ref_file, "rb").read() == open(PRACTICE3_5, "rb").read()
+    ls = rt.parse_scene_txt(PRACTICE3_5)
+    a = ls.arrays()
+    assert a["positions"].shape[0] == 24 and [p["kind"] for p in a["primitives"]] == [2, 2, 2, 2, 2, 1]
+    info = ls.info()
+    assert (info["width"], info["height"], info["samples"], int(a["ray_depth"])) == (512, 512, 64, 6)
+    fb, st = oracle.OracleScene(ls).run_raytracer(128, 128, 8, rng_mode=rt.RT_RNG_REFERENCE)
+    assert st["samples"] == 128 * 128 * 8 and np.isfinite(fb).all() and 0.01 < fb.mean() < 10
+
+
 def test_reference_sample_data_parses_if_present(rt, oracle):
     """Every scene file the reference ships under sample_data/ (BASELINE config 1 names scene-000.txt) goes through the
     loader and renders on the CPU oracle. Container only: /root/reference does not exist on the GPU box."""
