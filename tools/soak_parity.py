@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""tools/soak_parity.py [n_cases] [seed] — development aid: randomized parity soak on the GPU box.
+
+Each case draws a scene of the S-sponza family (triangle count, offsets, lights, materials, textures, alpha share, smooth normals, open or closed
+room, camera), an image shape, a sample count, a ray depth and the render knobs (ray-order key, packet mode, paths per pass, shard split), renders it
+through librt_amd.so in parity mode and compares with the CPU oracle: framebuffer bit for bit, every event counter. Then the production builds of the
+same scene (global-best pruning, device LBVH, the 8-wide tree from either builder) against the oracle's closest hits on random rays: t bit-equal, index
+differences only on exact ties, and their images within the production contract (pixels beyond 1e-5 relative are counted and must stay rare).
+Prints one line per case and a summary; exits non-zero on the first parity-mode difference."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+rt = importlib.import_module("raytracing-course-hw-public_amd")
+import oracle  # noqa: E402  (checker only)
+
+COUNTERS = ("samples", "casts", "nodes_visited", "box_tests", "tri_tests", "shaded_hits", "light_queries", "light_nodes", "light_box_tests",
+            "light_tri_tests", "light_hits", "texel_fetches")
+
+
+def random_rays(rng, lo, hi, n):
+    o = rng.uniform(lo, hi, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, d], axis=1).astype(np.float32)
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261005)
+    sg = rt.scenegen
+    sorts = (rt.RT_SORT_AUTO, rt.RT_SORT_OFF, rt.RT_SORT_CELL_OCTANT, rt.RT_SORT_OCTANT_CELL_CONE, rt.RT_SORT_OCTANT_FINE_CELL_CONE)
+    worst_prod = 0
+    only = int(os.environ.get("SOAK_ONLY", "-1"))  # replay one case of the sequence (same draws), with details on a production difference
+    t_start = time.time()
+    for case in range(n_cases):
+        n_tri = int(rng.choice([0, 1, 7, 60, 500, 4000, 30000]))
+        tex = int(rng.choice([0, 0, 4, 32, 64]))
+        kw = dict(seed=int(rng.integers(1, 2**31)), offset=float(rng.choice([0.05, 0.3, 1.5])), n_lights=int(rng.choice([0, 1, 3, 16, 40])),
+                  light_strength=float(rng.choice([5.0, 20.0])), n_materials=int(rng.choice([1, 5, 64])), tex_size=tex, n_tex_sets=int(rng.choice([1, 3, 16])),
+                  alpha_fraction=float(rng.choice([0.0, 0.05, 0.5])), smooth_normals=bool(rng.integers(0, 2)), open_room=bool(rng.integers(0, 4) == 0),
+                  camera=sg.look_camera((float(rng.uniform(-18, 18)), float(rng.uniform(1, 15)), float(rng.uniform(-8, 8))), yaw_deg=float(rng.uniform(-180, 180)),
+                                        yfov=float(rng.uniform(0.4, 1.4))))
+        sc = sg.room_scene(n_tri, **kw)
+        W, H, SPP = int(rng.integers(1, 200)), int(rng.integers(1, 160)), int(rng.choice([1, 2, 5, 16, 37]))
+        if rng.integers(0, 6) == 0:  # now and then a queue long enough for wf_shade's class-sorted windows (>= 2 M sorted rays)
+            W, H, SPP = 640, int(rng.integers(500, 700)), 8
+        depth = int(rng.choice([1, 2, 3, 8, 8, 12]))
+        sc.ray_depth = depth
+        knobs = dict(sort_mode=int(rng.choice(sorts)), packet_mode=int(rng.choice([rt.RT_PACKET_AUTO, rt.RT_PACKET_OFF, rt.RT_PACKET_ON])))
+        if rng.integers(0, 3) == 0:
+            knobs["max_paths"] = int(rng.choice([1024, 5000, 70000, 1 << 20]))
+        seed = int(rng.integers(0, 2**31))
+        if only >= 0 and case != only:  # replay: draw what the case would have drawn, render nothing
+            if rng.integers(0, 2) == 0:
+                rng.choice([2, 3, 8]), rng.choice([1, 64, 256, 1000])
+            random_rays(rng, np.zeros(3), np.ones(3), 4000)
+            continue
+        dev = rt.DeviceScene(sc)
+        orc = oracle.OracleScene(sc)
+        try:
+            ofb, ost = orc.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed)
+            gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, counters=True, **knobs)
+            ok = np.array_equal(gfb.view(np.uint32), ofb.view(np.uint32)) and all(gst[k] == ost[k] for k in COUNTERS)
+            if ok and rng.integers(0, 2) == 0:  # the split render: union of the shards
+                cnt = int(rng.choice([2, 3, 8]))
+                blk = int(rng.choice([1, 64, 256, 1000]))
+                sh = np.zeros_like(ofb)
+                for r in range(cnt):
+                    dev.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, shard_index=r, shard_count=cnt, shard_block=blk, out=sh)
+                ok = np.array_equal(sh.view(np.uint32), ofb.view(np.uint32))
+            line = f"case {case:3d}: tris {n_tri:6d} tex {tex:3d} lights {kw['n_lights']:2d} {W:3d}x{H:3d}x{SPP:2d} depth {depth:2d} {knobs} -> parity {'OK' if ok else 'DIFFERS'}"
+            if not ok:
+                bad = int((gfb.view(np.uint32) != ofb.view(np.uint32)).any(axis=2).sum())
+                print(line, f"({bad} pixels; counters {[k for k in COUNTERS if gst[k] != ost[k]]}); scene kwargs {kw}, seed {seed}", flush=True)
+                sys.exit(1)
+            # production builds against the oracle
+            lo, hi = np.array([-20.0, 0.0, -10.0]), np.array([20.0, 16.0, 10.0])
+            rays = random_rays(rng, lo, hi, 4000)
+            op, ob = orc.cast_rays(rays)
+            prod = []
+            for what, build, mode in (("gbest", {}, rt.RT_CAST_EXTEND_GLOBAL), ("lbvh", dict(device_bvh=True), rt.RT_CAST_EXTEND), ("wide-host", dict(wide=True), rt.RT_CAST_EXTEND),
+                                      ("wide-dev", dict(wide=True, device_bvh=True), rt.RT_CAST_EXTEND)):
+                if sc.n_triangles == 0:  # an empty scene (open room, no random triangles): nothing to build a production tree from
+                    break
+                sc2 = dev if not build else rt.DeviceScene(sc, **build)
+                try:
+                    gp, gb, _ = sc2.cast_rays_ex(rays, mode)
+                    hit_same = np.array_equal(op == 0xFFFFFFFF, gp == 0xFFFFFFFF)
+                    t_bad = int((ob[:, 2].view(np.uint32) != gb[:, 2].view(np.uint32)).sum())
+                    closer = int((gb[:, 2] < ob[:, 2]).sum())
+                    ties = int(((op != gp) & (ob[:, 2].view(np.uint32) == gb[:, 2].view(np.uint32))).sum())
+                    pfb, _ = sc2.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, global_best=mode == rt.RT_CAST_EXTEND_GLOBAL)
+                    rel = np.abs(pfb - ofb) / np.maximum(np.abs(ofb), 1e-3)
+                    beyond = int((rel > 1e-5).any(axis=2).sum())
+                    worst_prod = max(worst_prod, beyond)
+                    farther = t_bad - closer
+                    prod.append(f"{what}: t!= {t_bad} (closer {closer}) ties {ties} px>1e-5 {beyond}/{W * H}")
+                    if only >= 0:
+                        for i in np.nonzero(ob[:, 2].view(np.uint32) != gb[:, 2].view(np.uint32))[0][:8]:
+                            print(f"    ray {i}: o {rays[i, :3].tolist()} d {rays[i, 3:].tolist()} oracle prim {op[i]} bct {ob[i].tolist()} | {what} prim {gp[i]} bct {gb[i].tolist()}")
+                    if (not hit_same or farther > 0) and only < 0:
+                        print(line, "| PRODUCTION", what, "hit/miss differs" if not hit_same else f"{farther} rays with a FARTHER hit than the oracle", f"; scene kwargs {kw}", flush=True)
+                        sys.exit(2)
+                finally:
+                    if build:
+                        sc2.close()
+            print(line, "|", "; ".join(prod), flush=True)
+        finally:
+            dev.close()
+            orc.close()
+    print(f"{n_cases} cases, parity mode bit-exact in all; production images: at most {worst_prod} pixels beyond 1e-5 relative in a case; {time.time() - t_start:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
