@@ -60,6 +60,7 @@ def main():
         if only >= 0 and case != only:  # replay: draw what the case would have drawn, render nothing
             if rng.integers(0, 2) == 0:
                 rng.choice([2, 3, 8]), rng.choice([1, 64, 256, 1000])
+            rng.integers(0, 3), rng.integers(0, 3)
             random_rays(rng, np.zeros(3), np.ones(3), 4000)
             continue
         dev = rt.DeviceScene(sc)
@@ -75,6 +76,14 @@ def main():
                 for r in range(cnt):
                     dev.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, shard_index=r, shard_count=cnt, shard_block=blk, out=sh)
                 ok = np.array_equal(sh.view(np.uint32), ofb.view(np.uint32))
+            if ok and rng.integers(0, 3) == 0:  # the reference's own RNG stream (minstd per 256-pixel span, glibc sinf / cosf): the megakernel path
+                w2, h2, s2 = min(W, 96), min(H, 64), min(SPP, 5)
+                rfb, _ = dev.run_raytracer(w2, h2, s2, rng_mode=rt.RT_RNG_REFERENCE)
+                orf, _ = orc.run_raytracer(w2, h2, s2, rng_mode=rt.RT_RNG_REFERENCE)
+                ok = np.array_equal(rfb.view(np.uint32), orf.view(np.uint32))
+            if ok and rng.integers(0, 3) == 0:  # the device film: bytes of the host film applied to the oracle's image
+                img, _ = dev.run_raytracer_rgb8(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, **knobs)
+                ok = np.array_equal(img, oracle.tonemap(ofb))
             line = f"case {case:3d}: tris {n_tri:6d} tex {tex:3d} lights {kw['n_lights']:2d} {W:3d}x{H:3d}x{SPP:2d} depth {depth:2d} {knobs} -> parity {'OK' if ok else 'DIFFERS'}"
             if not ok:
                 bad = int((gfb.view(np.uint32) != ofb.view(np.uint32)).any(axis=2).sum())
