@@ -441,7 +441,10 @@ __global__ __launch_bounds__(256) void k_ploc_nn(const Ploc P) {
             u[3 + c] = fmaxf(bi[3 + c], bjx[3 + c]);
         }
         const float a = box_area6(u);
-        if (a < best) { // ascending j: on equal areas the lower position wins, on both sides of a pair
+        // ascending j: on equal areas the lower position wins, on both sides of a pair — except that the position's pairing partner i ^ 1 wins every
+        // tie it takes part in: when ALL areas tie (clusters collapsed onto a line or a point: zero-area unions) every position would otherwise choose
+        // its lowest neighbour, only positions 0 and 1 would choose each other, and a round would merge ONE pair (found by tools/soak_wide_rays.py)
+        if (a < best || (a == best && j == (i ^ 1))) {
             best = a;
             bj = j;
         }
@@ -922,7 +925,7 @@ hipError_t build_bvh_device(const rt_scene_desc *d, hipStream_t stream, DeviceBv
             BUILD_TRY(hipMemcpyAsync(&last[1], P.valid + (P.m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             BUILD_TRY(hipStreamSynchronize(stream));
             const uint32_t m_new = last[0] + last[1];
-            P.force = m_new == P.m ? 1 : 0; // no progress: pair neighbours next round
+            P.force = (uint64_t)(P.m - m_new) * 32u < P.m ? 1 : 0; // (next to) no progress — a healthy round merges a quarter of the clusters —: pair neighbours next round
             P.m = m_new;
             P.cur ^= 1;
             if (++rounds > 4096) {

@@ -168,3 +168,49 @@ def test_device_lbvh_invariants_and_closest_hits(gpu, oracle, sg, case, monkeypa
     finally:
         orc.close()
         dev.close()
+
+
+def test_ploc_terminates_on_collapsed_geometry(gpu, oracle, sg):
+    """Found by tools/soak_wide_rays.py: 20 000 triangles of a needle-shaped soup 4096 extents away from the origin, where float32 leaves the y and z
+    coordinates one or two distinct values. Every cluster union then has the same (zero) surface area; PLOC's nearest-neighbour search, which used to
+    resolve ties to the lowest position, merged ONE pair per round and gave up after 4096 rounds (RT_ERR_HIP "PLOC did not terminate"). Now the pairing
+    partner wins ties and a round that merges less than 1/32 of the clusters is followed by a forced pairing round: the build finishes, the tree is a
+    proper BVH over all triangles, and its closest hits are the oracle's up to the coordinates' own resolution (hit / miss equal; the wide tree: nothing lost, nothing farther)."""
+    rng = np.random.default_rng(56)
+    n, scale = 20_000, float(2 ** 17)
+    shape = np.array([1.0, 1e-4, 1e-4])
+    offset = np.array([-0.6, 0.8, -0.7]) * 4096 * scale
+    c = rng.uniform(-1.0, 1.0, size=(n, 1, 3)) * shape
+    pos = ((c + rng.uniform(-1.0, 1.0, size=(n, 3, 3)) * 0.1 * shape) * scale + offset).astype(np.float32)
+    assert len(np.unique(pos[..., 1])) <= 4 and len(np.unique(pos[..., 2])) <= 4  # the collapse this test is about
+    tang = np.tile(np.array([1, 0, 0], dtype=np.float32), (n, 3, 1))
+    sc = sg.Scene(positions=pos, normals=None, texcoords=np.zeros((n, 3, 2), np.float32), tangents=tang, material_ids=np.zeros(n, np.uint32),
+                  materials=[sg.Material(color=(0.7, 0.7, 0.7, 1.0), roughness=1.0, metallic=0.0)], textures=[],
+                  camera=sg.look_camera(tuple(float(v) for v in offset + np.array([0.0, 0.0, 3.0 * scale])), yaw_deg=0.0, yfov=0.9))
+    rays = random_rays(sc, 20_000, seed=3)
+    orc = oracle.OracleScene(sc)
+    try:
+        op, ob = orc.cast_rays(rays)
+        for kw in (dict(device_bvh=True), dict(device_bvh=True, wide=True)):
+            dev = gpu.DeviceScene(sc, **kw)  # raised RT_ERR_HIP before the fix
+            try:
+                if not kw.get("wide"):
+                    depth = _check_invariants(dev.bvh_device_dump(0), sc.positions)
+                    assert depth <= 62
+                gp, gb, _ = dev.cast_rays_ex(rays, gpu.RT_CAST_EXTEND)
+                if kw.get("wide"):  # the superset contract: nothing lost, nothing farther
+                    assert not ((gp == 0xFFFFFFFF) & (op != 0xFFFFFFFF)).any()
+                    both = (gp != 0xFFFFFFFF) & (op != 0xFFFFFFFF)
+                    assert (gb[both, 2] <= ob[both, 2]).all()
+                else:
+                    assert np.array_equal(gp == 0xFFFFFFFF, op == 0xFFFFFFFF)
+                    both = op != 0xFFFFFFFF
+                    # which of several coincident candidates the reference's pruning rule finds depends on the tree; their computed distances differ by
+                    # what the COORDINATES resolve here (ulp of 3e8 = 32, against extents of 26 in y and z), not by an ulp of t
+                    tol = 8.0 * float(np.spacing(np.float32(np.abs(pos).max())))
+                    assert np.abs(gb[both, 2].astype(np.float64) - ob[both, 2].astype(np.float64)).max(initial=0.0) <= tol
+            finally:
+                dev.close()
+    finally:
+        orc.close()
+
