@@ -53,6 +53,8 @@ def main():
             W, H, SPP = 640, int(rng.integers(500, 700)), 8
         depth = int(rng.choice([1, 2, 3, 8, 8, 12]))
         sc.ray_depth = depth
+        if kw["open_room"] and tex > 0 and rng.integers(0, 2) == 0:  # an environment map (Scene::bg, scene.h:81-89): any RGBA8 picture serves as the equirect image
+            sc.bg_texture = int(rng.integers(0, len(sc.textures)))
         knobs = dict(sort_mode=int(rng.choice(sorts)), packet_mode=int(rng.choice([rt.RT_PACKET_AUTO, rt.RT_PACKET_OFF, rt.RT_PACKET_ON])))
         if rng.integers(0, 3) == 0:
             knobs["max_paths"] = int(rng.choice([1024, 5000, 70000, 1 << 20]))

@@ -145,6 +145,27 @@ def main():
                     msgs.append("ok")
                 finally:
                     dev.close()
+            # the binary device trees (PLOC, radix) under the reference's traversal: hit / miss as the oracle, t as the oracle's up to the coordinates' resolution
+            # (which of several candidates within rounding the reference's pruning rule finds depends on the tree: DESIGN.md, production contract)
+            for kw in (dict(device_bvh=True), dict(device_bvh=True, device_builder=rt.RT_BUILDER_LBVH)):
+                dev = rt.DeviceScene(sc, **kw)
+                try:
+                    for mode in (rt.RT_CAST_EXTEND, rt.RT_CAST_EXTEND_GLOBAL):
+                        gp, gb, _ = dev.cast_rays_ex(rays, mode)
+                        miss_o, miss_g = op == 0xFFFFFFFF, gp == 0xFFFFFFFF
+                        both = ~miss_o & ~miss_g & ~degenerate
+                        mag = np.maximum(np.abs(rays[:, :3]).max(axis=1), float(np.abs(sc.positions).max())).astype(np.float64)
+                        tol = 4.0 * np.spacing(ob[both, 2]).astype(np.float64) + 8.0 * 2.0 ** -24 * mag[both]
+                        dt = np.abs(gb[both, 2].astype(np.float64) - ob[both, 2].astype(np.float64))
+                        flips = int(((miss_o != miss_g) & ~degenerate).sum())
+                        if flips or (dt > tol).any():
+                            i = int(np.flatnonzero((miss_o != miss_g) & ~degenerate)[0]) if flips else int(np.flatnonzero(both)[np.argmax(dt - tol)])
+                            print(f"\ncase {case}: binary tree {kw} mode {mode}: hit/miss flips on ordinary rays {flips}, worst |dt| - tol {float((dt - tol).max(initial=0.0)):.3e}", flush=True)
+                            print(f"   ray {i}: {rays[i].tolist()} oracle prim {op[i]} bct {ob[i].tolist()} gpu prim {gp[i]} bct {gb[i].tolist()}")
+                            sys.exit(1)
+                    msgs.append("bin ok")
+                finally:
+                    dev.close()
             print(f"hits {int((op != 0xFFFFFFFF).sum())}/6000 -> {msgs}", flush=True)
         finally:
             orc.close()
