@@ -63,6 +63,8 @@ def main():
             if rng.integers(0, 2) == 0:
                 rng.choice([2, 3, 8]), rng.choice([1, 64, 256, 1000])
             rng.integers(0, 3), rng.integers(0, 3)
+            if rng.integers(0, 4) == 0:
+                rng.choice([2, 3, 4]), rng.choice([0, 64, 256, 1000])
             random_rays(rng, np.zeros(3), np.ones(3), 4000)
             continue
         dev = rt.DeviceScene(sc)
@@ -86,6 +88,14 @@ def main():
             if ok and rng.integers(0, 3) == 0:  # the device film: bytes of the host film applied to the oracle's image
                 img, _ = dev.run_raytracer_rgb8(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, **knobs)
                 ok = np.array_equal(img, oracle.tonemap(ofb))
+            if ok and rng.integers(0, 4) == 0:  # the library's own multi-GPU scene: G replicas on GPU 0 over the peer-copy rehearsal transport (csrc/rt_group.cpp)
+                G, blk = int(rng.choice([2, 3, 4])), int(rng.choice([0, 64, 256, 1000]))
+                grp = rt.DeviceScene(sc, device=[0] * G, build_flags=rt.RT_BUILD_GROUP_COPY)
+                try:
+                    gg, _ = grp.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, shard_block=blk, **knobs)
+                    ok = np.array_equal(gg.view(np.uint32), ofb.view(np.uint32))
+                finally:
+                    grp.close()
             line = f"case {case:3d}: tris {n_tri:6d} tex {tex:3d} lights {kw['n_lights']:2d} {W:3d}x{H:3d}x{SPP:2d} depth {depth:2d} {knobs} -> parity {'OK' if ok else 'DIFFERS'}"
             if not ok:
                 bad = int((gfb.view(np.uint32) != ofb.view(np.uint32)).any(axis=2).sum())
