@@ -53,6 +53,24 @@ def main():
             W, H, SPP = 640, int(rng.integers(500, 700)), 8
         depth = int(rng.choice([1, 2, 3, 8, 8, 12]))
         sc.ray_depth = depth
+        if rng.integers(0, 3) == 0:  # texture coordinates far outside [0, 1): the wrap-around texel path (Texture::sample, geometry.h:545-575), negative and huge values
+            U, V = float(rng.choice([-3.0, 7.5, 1e3, 1e6])), float(rng.choice([0.0, -0.25, 123.456]))
+            sc.texcoords = (sc.texcoords * np.float32(U) + np.float32(V)).astype(np.float32)
+        if rng.integers(0, 3) == 0:  # materials at the ends of their ranges: mirror-smooth, fully rough, metal / dielectric, invisible, odd ior, an emissive texture
+            for m in sc.materials[2:]:
+                r = int(rng.integers(0, 8))
+                if r == 0:
+                    m.roughness = 0.0
+                elif r == 1:
+                    m.metallic, m.roughness = 1.0, 0.0
+                elif r == 2:
+                    m.metallic = 0.0
+                elif r == 3:
+                    m.color = (m.color[0], m.color[1], m.color[2], 0.0)
+                elif r == 4:
+                    m.ior = float(rng.choice([1.0, 1.0001, 3.0]))
+                elif r == 5 and sc.textures:
+                    m.emissive_tex, m.emission, m.emissive_strength = int(rng.integers(0, len(sc.textures))), (1.0, 0.5, 0.25), 2.0
         if kw["open_room"] and tex > 0 and rng.integers(0, 2) == 0:  # an environment map (Scene::bg, scene.h:81-89): any RGBA8 picture serves as the equirect image
             sc.bg_texture = int(rng.integers(0, len(sc.textures)))
         knobs = dict(sort_mode=int(rng.choice(sorts)), packet_mode=int(rng.choice([rt.RT_PACKET_AUTO, rt.RT_PACKET_OFF, rt.RT_PACKET_ON])))
