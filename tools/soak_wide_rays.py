@@ -30,6 +30,24 @@ def make_scene(sg, rng, n, scale, offset, shape):
         k = rng.integers(0, n, size=max(1, n // 4))
         ax = rng.integers(0, 3, size=len(k))
         pos[k, :, ax] = pos[k, 0:1, ax]
+    kind = int(rng.integers(0, 8))  # now and then a pathological arrangement
+    if kind == 0 and n >= 9:  # duplicates: a few distinct triangles, each many times (boxes that cannot be told apart)
+        pos = pos[rng.integers(0, max(1, n // 50), size=n)]
+    elif kind == 1 and n >= 9:  # one giant triangle over everything else
+        pos[0] = np.array([[-3.0, -3.0, 0.0], [3.0, -3.0, 0.1], [0.0, 3.0, -0.1]]) * shape
+    elif kind == 2:  # a fan: every triangle shares one vertex
+        pos[:, 0, :] = pos[0, 0, :]
+    elif kind == 3 and n >= 9:  # coplanar tiles on an axis-aligned grid: flat boxes, shared edges, exact ties everywhere
+        g = int(np.ceil(np.sqrt(n / 2)))
+        ij = np.stack(np.meshgrid(np.arange(g), np.arange(g), indexing="ij"), axis=-1).reshape(-1, 2)[: (n + 1) // 2]
+        a = np.concatenate([ij, np.zeros((len(ij), 1))], axis=1) / g * 2 - np.array([1.0, 1.0, 0.0])
+        q = np.stack([a, a + [2.0 / g, 0, 0], a + [0, 2.0 / g, 0]], axis=1)
+        r = np.stack([a + [2.0 / g, 2.0 / g, 0], a + [0, 2.0 / g, 0], a + [2.0 / g, 0, 0]], axis=1)
+        pos = np.concatenate([q, r], axis=0)[:n] * shape
+    elif kind == 4 and n >= 9:  # sizes growing geometrically along a line
+        s_ = np.exp(np.linspace(np.log(1e-4), 0.0, n))[:, None, None]
+        pos = (np.cumsum(s_, axis=0) / s_.sum() * 2 - 1) * np.array([1.0, 0.0, 0.0]) + rng.uniform(-1.0, 1.0, size=(n, 3, 3)) * s_
+        pos = pos * shape
     pos = (pos * scale + offset).astype(np.float32)
     tang = np.tile(np.array([1, 0, 0], dtype=np.float32), (n, 3, 1))
     mats = [sg.Material(color=(0.7, 0.6, 0.5, 1.0), roughness=0.6, metallic=0.2)]
@@ -72,6 +90,10 @@ def true_hit(P, ray, prim, t):
     """float64 Cramer solution of `ray` against triangle `prim`: inside (1e-5 slack) and at the reported distance (1e-5 relative)."""
     a, b, c = P[prim]
     oo, dd = ray[:3].astype(np.float64), ray[3:].astype(np.float64)
+    edge = max(np.linalg.norm(b - a), np.linalg.norm(c - a), np.linalg.norm(c - b))
+    mag = max(np.abs(P[prim]).max(), np.abs(oo).max())
+    if edge == 0.0 or np.linalg.norm(np.cross(b - a, c - a)) / edge < 64.0 * float(np.spacing(np.float32(mag))):
+        return True  # a sliver thinner than the coordinates resolve: inside / outside is not decidable from the float32 vertices
     m = np.stack([b - a, c - a, -dd], axis=1)
     try:
         x = np.linalg.solve(m, oo - a)
@@ -87,7 +109,7 @@ def main():
     t0 = time.time()
     refused = closer_total = ties_total = new_total = 0
     for case in range(n_cases):
-        n = int(rng.choice([1, 3, 9, 40, 300, 3000, 20000]))
+        n = int(rng.choice([1, 3, 9, 40, 300, 3000, 20000, 20000, 250000]))
         k = int(rng.integers(-30, 41))
         scale = float(2.0 ** k)
         shape = np.array(rng.choice([[1, 1, 1], [1, 1, 1e-3], [1, 1e-4, 1e-4], [1, 0.3, 0.05]]), dtype=np.float64)
