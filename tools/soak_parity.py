@@ -37,10 +37,13 @@ def main():
     sg = rt.scenegen
     sorts = (rt.RT_SORT_AUTO, rt.RT_SORT_OFF, rt.RT_SORT_CELL_OCTANT, rt.RT_SORT_OCTANT_CELL_CONE, rt.RT_SORT_OCTANT_FINE_CELL_CONE)
     worst_prod = 0
+    big = os.environ.get("SOAK_BIG") == "1"  # trees far beyond the caches: 2e5 - 3e6 triangles, every 16th 256-pixel span of a 512 x 512 image against the oracle
     only = int(os.environ.get("SOAK_ONLY", "-1"))  # replay one case of the sequence (same draws), with details on a production difference
     t_start = time.time()
     for case in range(n_cases):
         n_tri = int(rng.choice([0, 1, 7, 60, 500, 4000, 30000]))
+        if big:
+            n_tri = int(rng.choice([200_000, 1_000_000, 3_000_000]))
         tex = int(rng.choice([0, 0, 4, 32, 64]))
         kw = dict(seed=int(rng.integers(1, 2**31)), offset=float(rng.choice([0.05, 0.3, 1.5])), n_lights=int(rng.choice([0, 1, 3, 16, 40])),
                   light_strength=float(rng.choice([5.0, 20.0])), n_materials=int(rng.choice([1, 5, 64])), tex_size=tex, n_tex_sets=int(rng.choice([1, 3, 16])),
@@ -51,6 +54,8 @@ def main():
         W, H, SPP = int(rng.integers(1, 200)), int(rng.integers(1, 160)), int(rng.choice([1, 2, 5, 16, 37]))
         if rng.integers(0, 6) == 0:  # now and then a queue long enough for wf_shade's class-sorted windows (>= 2 M sorted rays)
             W, H, SPP = 640, int(rng.integers(500, 700)), 8
+        if big:
+            W, H, SPP = 512, 512, 4
         depth = int(rng.choice([1, 2, 3, 8, 8, 12]))
         sc.ray_depth = depth
         if rng.integers(0, 3) == 0:  # texture coordinates far outside [0, 1): the wrap-around texel path (Texture::sample, geometry.h:545-575), negative and huge values
@@ -88,25 +93,35 @@ def main():
         dev = rt.DeviceScene(sc)
         orc = oracle.OracleScene(sc)
         try:
-            ofb, ost = orc.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed)
-            gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, counters=True, **knobs)
+            if big:  # the same shard on both sides: spans 3, 19, 35, ... of the image
+                ofb = np.zeros((H, W, 3), dtype=np.float32)
+                gfb = np.zeros((H, W, 3), dtype=np.float32)
+                _, ost = orc.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, shard_index=3, shard_count=16, shard_block=256, out=ofb)
+                _, gst = dev.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, counters=True, shard_index=3, shard_count=16, shard_block=256, out=gfb, **knobs)
+            else:
+                ofb, ost = orc.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed)
+                gfb, gst = dev.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, counters=True, **knobs)
             ok = np.array_equal(gfb.view(np.uint32), ofb.view(np.uint32)) and all(gst[k] == ost[k] for k in COUNTERS)
-            if ok and rng.integers(0, 2) == 0:  # the split render: union of the shards
+            if ok and big:  # the whole image in both schedules: wavefront pipeline == persistent megakernel
+                a, _ = dev.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, **knobs)
+                m, _ = dev.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, megakernel=True)
+                ok = np.array_equal(a.view(np.uint32), m.view(np.uint32)) and np.array_equal(a.reshape(-1, 3)[gfb.reshape(-1, 3)[:, 0] != 0].view(np.uint32), gfb.reshape(-1, 3)[gfb.reshape(-1, 3)[:, 0] != 0].view(np.uint32))
+            if ok and rng.integers(0, 2) == 0 and not big:  # the split render: union of the shards
                 cnt = int(rng.choice([2, 3, 8]))
                 blk = int(rng.choice([1, 64, 256, 1000]))
                 sh = np.zeros_like(ofb)
                 for r in range(cnt):
                     dev.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, shard_index=r, shard_count=cnt, shard_block=blk, out=sh)
                 ok = np.array_equal(sh.view(np.uint32), ofb.view(np.uint32))
-            if ok and rng.integers(0, 3) == 0:  # the reference's own RNG stream (minstd per 256-pixel span, glibc sinf / cosf): the megakernel path
+            if ok and rng.integers(0, 3) == 0 and not big:  # the reference's own RNG stream (minstd per 256-pixel span, glibc sinf / cosf): the megakernel path
                 w2, h2, s2 = min(W, 96), min(H, 64), min(SPP, 5)
                 rfb, _ = dev.run_raytracer(w2, h2, s2, rng_mode=rt.RT_RNG_REFERENCE)
                 orf, _ = orc.run_raytracer(w2, h2, s2, rng_mode=rt.RT_RNG_REFERENCE)
                 ok = np.array_equal(rfb.view(np.uint32), orf.view(np.uint32))
-            if ok and rng.integers(0, 3) == 0:  # the device film: bytes of the host film applied to the oracle's image
+            if ok and rng.integers(0, 3) == 0 and not big:  # the device film: bytes of the host film applied to the oracle's image
                 img, _ = dev.run_raytracer_rgb8(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, **knobs)
                 ok = np.array_equal(img, oracle.tonemap(ofb))
-            if ok and rng.integers(0, 4) == 0:  # the library's own multi-GPU scene: G replicas on GPU 0 over the peer-copy rehearsal transport (csrc/rt_group.cpp)
+            if ok and rng.integers(0, 4) == 0 and not big:  # the library's own multi-GPU scene: G replicas on GPU 0 over the peer-copy rehearsal transport (csrc/rt_group.cpp)
                 G, blk = int(rng.choice([2, 3, 4])), int(rng.choice([0, 64, 256, 1000]))
                 grp = rt.DeviceScene(sc, device=[0] * G, build_flags=rt.RT_BUILD_GROUP_COPY)
                 try:
@@ -135,7 +150,11 @@ def main():
                     t_bad = int((ob[:, 2].view(np.uint32) != gb[:, 2].view(np.uint32)).sum())
                     closer = int((gb[:, 2] < ob[:, 2]).sum())
                     ties = int(((op != gp) & (ob[:, 2].view(np.uint32) == gb[:, 2].view(np.uint32))).sum())
-                    pfb, _ = sc2.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, global_best=mode == rt.RT_CAST_EXTEND_GLOBAL)
+                    if big:
+                        pfb = np.zeros((H, W, 3), dtype=np.float32)
+                        sc2.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, global_best=mode == rt.RT_CAST_EXTEND_GLOBAL, shard_index=3, shard_count=16, shard_block=256, out=pfb)
+                    else:
+                        pfb, _ = sc2.run_raytracer(W, H, SPP, rng_mode=rt.RT_RNG_DEVICE, seed=seed, global_best=mode == rt.RT_CAST_EXTEND_GLOBAL)
                     rel = np.abs(pfb - ofb) / np.maximum(np.abs(ofb), 1e-3)
                     beyond = int((rel > 1e-5).any(axis=2).sum())
                     worst_prod = max(worst_prod, beyond)
